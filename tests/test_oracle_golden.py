@@ -1,0 +1,85 @@
+"""Pins the CPU oracle (oracle/ref_unet.py) against outputs of the reference itself
+(tests/golden/*.npz, made by tools/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe, ref_unet
+
+
+def sig(t):
+    f = t.detach().double().flatten()
+    idx = torch.linspace(0, f.numel() - 1, 16).long()
+    return np.concatenate([[f.norm().item(), f.sum().item(), f.abs().sum().item()], f[idx].numpy()])
+
+
+def _close(a, b, rtol=2e-5, atol=2e-6):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def _sig_close(a, b, rtol=2e-4):
+    # norm / abs-sum are well conditioned; the plain sum and samples get an absolute floor
+    a, b = np.asarray(a), np.asarray(b)
+    floor = 1e-6 * max(1.0, abs(b[2]))
+    np.testing.assert_allclose(a[[0, 2]], b[[0, 2]], rtol=rtol)
+    np.testing.assert_allclose(a[1], b[1], rtol=rtol, atol=floor * 10)
+    np.testing.assert_allclose(a[3:], b[3:], rtol=rtol, atol=rtol * (b[0] / max(1, len(b)) + 1e-7))
+
+
+@pytest.mark.parametrize("name", ["unet_1_2_8", "unet_3_4_8", "unet_c1"])
+def test_unet_matches_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cin, ncls, feat = int(g["cin"]), int(g["ncls"]), int(g["feat"])
+    B, H, W, seed = int(g["B"]), int(g["H"]), int(g["W"]), int(g["seed"])
+    torch.manual_seed(0)
+    m = ref_unet.RefUNet(cin, ncls, feat, False)
+    assert len(m.state_dict()) == 118
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed))
+    x, lab = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    m.train()
+    steps = 3 if "loss2" in g else 1
+    for step in range(steps):
+        logits = m(x)
+        loss = ref_unet.dice_bce_mc(logits, lab, ncls)
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            _sig_close(sig(logits), g["logits_sig"])
+            if "logits" in g:
+                _close(logits.detach().numpy(), g["logits"])
+            am = logits.argmax(1).numpy().astype(np.uint8)
+            margin = torch.topk(logits.detach(), 2, dim=1).values
+            margin = (margin[:, 0] - margin[:, 1]).numpy()
+            safe = margin > 1e-5
+            assert (am == g["argmax"])[safe].all()
+            for k, p in m.named_parameters():
+                _sig_close(sig(p.grad), g["grad_sig." + k], rtol=5e-4)
+        assert abs(loss.item() - float(g[f"loss{step}"])) < 2e-6
+        opt.step()
+        if step in (0, steps - 1):
+            for k, v in m.state_dict().items():
+                _sig_close(sig(v.float()), g[f"after{step + 1}." + k], rtol=5e-4)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)
+    _sig_close(sig(ev), g["eval_logits_sig"], rtol=5e-4)
+    if "eval_logits" in g:
+        _close(ev.numpy(), g["eval_logits"], rtol=2e-4, atol=2e-5)
+
+
+def test_state_dict_keys_and_shapes():
+    m = ref_unet.RefUNet(3, 4, 64)
+    sd = m.state_dict()
+    assert len(sd) == 118
+    assert sd["inc.double_conv.0.weight"].shape == (64, 3, 3, 3)
+    assert sd["down4.maxpool_conv.1.double_conv.3.weight"].shape == (1024, 1024, 3, 3)
+    assert sd["up1.up.weight"].shape == (1024, 512, 2, 2)
+    assert sd["up1.conv.double_conv.0.weight"].shape == (512, 1024, 3, 3)
+    assert sd["outc.conv.bias"].shape == (4,)
+    assert sum(p.numel() for p in m.parameters()) == 31_037_828
+    m2 = ref_unet.RefUNet(-1, 2, 8, dropout=True)
+    assert "down1.maxpool_conv.2.double_conv.0.weight" in m2.state_dict()
+    assert m2.n_channels == 1

@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+Imports /root/reference with three stub modules for packages its files import at
+module level but never touch on the hot path: `torchvision`
+(Model.py:3, unused), `cv2` (loss.py:8, unused on 'dice_bce_mc'), `ml_collections`
+(vit_seg_configs.py:1, only ConfigDict).  Weights and inputs come from
+oracle/recipe.py (build-owned seeds), so only numeric *outputs* of the reference are
+serialised.  /root/reference never travels to the GPU box; these fixtures do.
+
+Usage:  python tools/gen_golden.py [--only unet|blocks|trainer|transunet] [--big]
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("UMI_REFERENCE", "/root/reference")
+GOLD = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+from oracle import recipe  # noqa: E402
+
+
+class _ConfigDict(dict):
+    """Minimal stand-in for ml_collections.ConfigDict (attr + item access)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        for key, v in list(self.items()):
+            if isinstance(v, dict) and not isinstance(v, _ConfigDict):
+                self[key] = _ConfigDict(v)
+
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def import_reference():
+    for name in ("torchvision", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    mc = types.ModuleType("ml_collections")
+    mc.ConfigDict = _ConfigDict
+    sys.modules.setdefault("ml_collections", mc)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    import Model, loss, Trainer  # noqa: E401
+    return Model, loss, Trainer
+
+
+def sig(t: torch.Tensor):
+    """Compact signature of a tensor: [l2 norm, sum, abs-sum] + 16 strided samples."""
+    f = t.detach().double().flatten()
+    idx = torch.linspace(0, f.numel() - 1, 16).long()
+    return np.concatenate([[f.norm().item(), f.sum().item(), f.abs().sum().item()],
+                           f[idx].numpy()])
+
+
+def meta():
+    return dict(torch_version=torch.__version__, threads=torch.get_num_threads())
+
+
+def margin_map(logits):
+    top2 = torch.topk(logits, 2, dim=1).values
+    return (top2[:, 0] - top2[:, 1]).float()
+
+
+# ---------------------------------------------------------------------------------------
+def gen_blocks(Model):
+    torch.manual_seed(0)
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # DoubleConv(3->8->8) on an odd-sized map, train and eval
+    dc = Model.DoubleConv(3, 8)
+    dc.load_state_dict(recipe.fill_state_dict(dc.state_dict(), seed=1))
+    x = torch.randn(2, 3, 17, 19, generator=g)
+    dc.train()
+    xr = x.clone().requires_grad_(True)
+    y = dc(xr)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out["dc_x"], out["dc_gy"] = x.numpy(), gy.numpy()
+    out["dc_train_y"] = y.detach().numpy()
+    out["dc_train_gx"] = xr.grad.numpy()
+    for k, p in dc.named_parameters():
+        out["dc_grad." + k] = p.grad.numpy()
+    for k, b in dc.named_buffers():
+        out["dc_buf." + k] = b.numpy()
+    dc.eval()
+    out["dc_eval_y"] = dc(x).detach().numpy()
+
+    # Down(8->16)
+    dn = Model.Down(8, 16)
+    dn.load_state_dict(recipe.fill_state_dict(dn.state_dict(), seed=2))
+    dn.train()
+    x = torch.randn(2, 8, 12, 20, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = dn(xr)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out["down_x"], out["down_gy"] = x.numpy(), gy.numpy()
+    out["down_y"], out["down_gx"] = y.detach().numpy(), xr.grad.numpy()
+    for k, p in dn.named_parameters():
+        out["down_grad." + k] = p.grad.numpy()
+
+    # Up(16->8), skip larger by an odd amount => pad path (Model.py:69-73)
+    up = Model.Up(16, 8)
+    up.load_state_dict(recipe.fill_state_dict(up.state_dict(), seed=3))
+    up.train()
+    x1 = torch.randn(2, 16, 5, 6, generator=g)
+    x2 = torch.randn(2, 8, 11, 13, generator=g)
+    x1r, x2r = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    y = up(x1r, x2r)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out["up_x1"], out["up_x2"], out["up_gy"] = x1.numpy(), x2.numpy(), gy.numpy()
+    out["up_y"] = y.detach().numpy()
+    out["up_gx1"], out["up_gx2"] = x1r.grad.numpy(), x2r.grad.numpy()
+    for k, p in up.named_parameters():
+        out["up_grad." + k] = p.grad.numpy()
+
+    # OutConv(8->3)
+    oc = Model.OutConv(8, 3)
+    oc.load_state_dict(recipe.fill_state_dict(oc.state_dict(), seed=4))
+    x = torch.randn(2, 8, 9, 7, generator=g)
+    out["outc_x"] = x.numpy()
+    out["outc_y"] = oc(x).detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, "unet_blocks.npz"), **out, **meta())
+    print("wrote unet_blocks.npz", len(out), "arrays")
+
+
+def gen_unet_case(Model, loss_mod, name, cin, ncls, feat, B, H, W, seed, full_logits=True,
+                  steps=3):
+    torch.manual_seed(0)
+    loss_mod.CLASS_NUMBER = ncls
+    m = Model.UNet(cin, ncls, feat, False)
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed))
+    x, lab = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    out = dict(cin=cin, ncls=ncls, feat=feat, B=B, H=H, W=W, seed=seed)
+    m.train()
+    for step in range(steps):
+        logits = m(x)
+        loss = loss_mod.calc_loss(logits, lab, loss_type="dice_bce_mc")
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out["logits_sig"] = sig(logits)
+            if full_logits:
+                out["logits"] = logits.detach().numpy()
+            out["argmax"] = logits.argmax(1).numpy().astype(np.uint8)
+            out["margin_min"] = margin_map(logits.detach()).min().item()
+            mm = margin_map(logits.detach())
+            out["margin_q"] = np.quantile(mm.numpy(), [0.0, 1e-4, 1e-3, 1e-2, 0.1, 0.5])
+            out["loss0"] = loss.item()
+            for k, p in m.named_parameters():
+                out["grad_sig." + k] = sig(p.grad)
+        out[f"loss{step}"] = loss.item()
+        opt.step()
+        if step in (0, steps - 1):
+            for k, v in m.state_dict().items():
+                out[f"after{step + 1}." + k] = sig(v.float())
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)
+    out["eval_logits_sig"] = sig(ev)
+    if full_logits:
+        out["eval_logits"] = ev.numpy()
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out, **meta())
+    print(f"wrote {name}.npz loss0={out['loss0']:.6f} margin_min={out['margin_min']:.3e}")
+
+
+def gen_trainer(Model, loss_mod, Trainer):
+    """Config 1 plumbing: reference Trainer on CPU, UNet(1,2,8) to keep it fast, plus the
+    same run's logged numbers.  (Config-1 proper, UNet(1,2,64) 256^2, is `unet_c1`.)"""
+    from torch.utils.data import DataLoader, TensorDataset
+    torch.manual_seed(0)
+    loss_mod.CLASS_NUMBER = 2
+    m = Model.UNet(1, 2, 8, False)
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=21))
+    xs, ls = recipe.synthetic_batch(6, 1, 32, 32, 2, seed=21)
+    loaders = {"train": DataLoader(TensorDataset(xs[:4], ls[:4]), batch_size=2, shuffle=False),
+               "val": DataLoader(TensorDataset(xs[4:], ls[4:]), batch_size=1)}
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    with tempfile.TemporaryDirectory() as d:
+        cwd = os.getcwd()
+        os.chdir(d)
+        tr = Trainer.Trainer(m, "single", torch.FloatTensor, "cpu", d, loaders, 2, opt, 25, 2,
+                             "dice_bce_mc", "dice_bce_mc", lr_scheduler=True)
+        tr.train()
+        os.chdir(cwd)
+        files = sorted(os.listdir(os.path.join(d, "models")))
+        log = open(os.path.join(d, "logs.txt")).read()
+    out = dict(train_loss=np.array(tr.train_loss_list), val_loss=np.array(tr.val_loss_list),
+               val_score=np.array(tr.val_score_list), iter_num=tr.iter_num,
+               final_lr=opt.param_groups[0]["lr"], files=np.array(files), log=np.array(log),
+               best_val_score=float(tr.best_val_score))
+    for k, v in m.state_dict().items():
+        out["final." + k] = sig(v.float())
+    np.savez_compressed(os.path.join(GOLD, "trainer_single.npz"), **out, **meta())
+    print("wrote trainer_single.npz", out["train_loss"], out["val_loss"], files)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--big", action="store_true", help="also config-1 scale UNet(1,2,64) 256^2")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    Model, loss_mod, Trainer = import_reference()
+    if a.only in (None, "blocks"):
+        gen_blocks(Model)
+    if a.only in (None, "unet"):
+        gen_unet_case(Model, loss_mod, "unet_1_2_8", 1, 2, 8, 2, 64, 64, seed=5)
+        gen_unet_case(Model, loss_mod, "unet_3_4_8", 3, 4, 8, 2, 48, 80, seed=6)
+        if a.big:
+            gen_unet_case(Model, loss_mod, "unet_c1", 1, 2, 64, 2, 256, 256, seed=7,
+                          full_logits=False, steps=1)
+    if a.only in (None, "trainer"):
+        gen_trainer(Model, loss_mod, Trainer)
+    if a.only in (None, "transunet"):
+        try:
+            from tools import gen_golden_transunet
+            gen_golden_transunet.run(import_reference, sig, meta, GOLD, big=a.big)
+        except ImportError:
+            print("transunet generator not present yet")
+
+
+if __name__ == "__main__":
+    main()
