@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: U-Net training step (forward + dice_bce_mc + backward + SGD), images/sec.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: UNet(1, 2, 64), 512x512, batch 16 per GPU, fp16 storage with fp32
+accumulation, synthetic data resident in HBM, random-init weights.  Weak scaling: per-GPU batch fixed,
+gradients averaged with one RCCL all-reduce per bucket.  Prints ONE JSON line on rank 0 carrying the
+`roofline` (dominant kernel = the 3x3 conv forward, timed live with HIP events) and `cpu_baseline`
+(the oracle's torch-CPU restatement timed on this box's host cores, rank 0 at N=1 only) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "unet-torch_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def unet_fwd_gflop_per_image(cin, ncls, f, H, W):
+    """2*MACs of conv / convT / 1x1 only."""
+    fl = 0.0
+    chans = [f * 2 ** i for i in range(5)]
+    h, w = H, W
+    prev = cin
+    for i, c in enumerate(chans):
+        if i:
+            h, w = h // 2, w // 2
+        fl += 2.0 * h * w * 9 * (prev * c + c * c)
+        prev = c
+    for i in range(4):
+        c = chans[3 - i]
+        h, w = h * 2, w * 2
+        fl += 2.0 * (h // 2) * (w // 2) * (2 * c) * c * 4            # ConvT 2x2
+        fl += 2.0 * h * w * 9 * (2 * c * c + c * c)
+    fl += 2.0 * H * W * f * ncls
+    return fl / 1e9
+
+
+def double_conv_shapes(cin, f, H, W, B):
+    """(name, N, H, W, Ci, Co) of the 18 3x3 convs of the nine DoubleConvs at this config."""
+    out, chans = [], [f * 2 ** i for i in range(5)]
+    h, w, prev = H, W, cin
+    for i, c in enumerate(chans):
+        if i:
+            h, w = h // 2, w // 2
+        out += [(f"enc{i}.c1", B, h, w, prev, c), (f"enc{i}.c2", B, h, w, c, c)]
+        prev = c
+    for i in range(4):
+        c = chans[3 - i]
+        h, w = h * 2, w * 2
+        out += [(f"dec{i}.c1", B, h, w, 2 * c, c), (f"dec{i}.c2", B, h, w, c, c)]
+    return out
+
+
+def measure_conv_roofline(device, dtype, cin, f, H, W, B, reps=5):
+    """Times every DoubleConv 3x3 forward launch of the workload with HIP events on the launch stream."""
+    from umi import ops
+    per = []
+    tot_fl, tot_t = 0.0, 0.0
+    for name, n, h, w, ci, co in double_conv_shapes(cin, f, H, W, B):
+        x = torch.randn(n, h, w, ci, device=device).to(dtype)
+        wgt = torch.randn(co, ci, 3, 3, device=device) * (2.0 / (9 * ci)) ** 0.5
+        tx = ops.passthrough_tx(ci, device)
+        tx[:, 3] = 0.0                                           # BN-apply + ReLU on load, like the real step
+        y = torch.empty(n, h, w, co, device=device, dtype=dtype)
+        wp = ops.pack_conv_fwd(wgt, dtype)
+        ops.conv_fwd(x, tx, wp, None, y, 3, 3, 1, 1, want_stats=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.conv_fwd(x, tx, wp, None, y, 3, 3, 1, 1, want_stats=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * n * h * w * 9 * ci * co
+        per.append({"conv": name, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2)})
+        if ci >= 16:                 # the Ci=1 stem is HBM-bound, not part of the MFMA roofline figure
+            tot_fl += fl
+            tot_t += ms
+        del x, y, wgt, wp
+    ach = tot_fl / tot_t / 1e9
+    return {"bound": "mfma", "kernel": "conv3x3 forward (+BN-stat epilogue, BN/ReLU-on-load), 17 DoubleConv launches",
+            "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None, "per_launch": per}
+
+
+def cpu_baseline(cin, ncls, f, H, W, budget_s=25.0):
+    """The oracle (torch CPU fp32 restatement of the reference) timed on this box's host cores."""
+    from oracle import recipe, ref_unet
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    m = ref_unet.RefUNet(cin, ncls, f, False).train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    B = 1
+    x, lab = recipe.synthetic_batch(B, cin, H, W, ncls, seed=1234)
+    ref_unet.train_step(m, opt, x, lab, ncls)                   # warm-up
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < budget_s and n < 3):
+        ref_unet.train_step(m, opt, x, lab, ncls)
+        n += 1
+    dt = (time.time() - t0) / n
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(B / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of UNet({cin},{ncls},{f}) batch {B} at {H}x{W}, fp32, torch CPU, after 1 warm-up",
+            "cpu": model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--features", type=int, default=64)
+    ap.add_argument("--cin", type=int, default=1)
+    ap.add_argument("--ncls", type=int, default=2)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import Model
+    import loss as L
+    from umi import ddp
+    L.CLASS_NUMBER = a.ncls
+    torch.manual_seed(0)                         # identical initial weights on every rank
+    model = Model.UNet(a.cin, a.ncls, a.features, compute_dtype=a.dtype).to(dev).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    reducer = ddp.GradReducer(model, world) if world > 1 else None
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    x = torch.randn(a.batch, a.cin, a.size, a.size, device=dev, generator=g)
+    labels = torch.randint(0, a.ncls, (a.batch, a.size, a.size), device=dev, generator=g).float()
+
+    def step():
+        logits = model(x)
+        loss = L.calc_loss(logits, labels, loss_type="dice_bce_mc")
+        opt.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            reducer.sync()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = a.batch * world * a.steps / dt
+        gf = unet_fwd_gflop_per_image(a.cin, a.ncls, a.features, a.size, a.size)
+        out = {
+            "metric": "images/sec training step, 4-level U-Net 1ch->2cls 512x512",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": f"UNet({a.cin},{a.ncls},{a.features}) train step (fwd + dice_bce_mc + bwd + SGD), "
+                                   f"{a.size}x{a.size}, batch {a.batch}/GPU, BASELINE configs[1]",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                       "algorithmic_tflops_per_gpu": round(3 * gf * a.batch * a.steps / dt / 1e3, 2)},
+            "final_loss": round(final_loss, 5),
+        }
+        if not a.no_roofline:
+            out["roofline"] = measure_conv_roofline(dev, torch.float16 if a.dtype == "fp16" else torch.float32,
+                                                    a.cin, a.features, a.size, a.size, a.batch)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cin, a.ncls, a.features, a.size, a.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+/* unetmi.h -- C ABI of libunetmi.so: the MI355X (gfx950) U-Net / TransUNet hot path.
+ *
+ * The reference (caki35/UNet-Torch) is pure Python and has no FFI of its own: every
+ * arithmetic op on its hot path is a torch.nn call.  The drop-in boundary
+ * is therefore the reference's Python module API (`Model.UNet`, `Trainer.Trainer`, ...,
+ * mirrored under unet-torch_amd/), and THIS header is the C ABI that mirror binds with
+ * ctypes.  Each entry point cites the reference call site whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; device pointers are borrowed from the caller
+ *    (torch tensor .data_ptr()); nothing is allocated, freed or synchronised inside.
+ *  - Every function enqueues on the caller's `stream` and returns an int:
+ *    0 = ok, <0 = UMI_ERR_*, >0 = hipError_t of the failed launch.  Nothing throws.
+ *  - Activations are NHWC with an explicit pixel stride `ld` (elements), so a tensor may
+ *    be a channel slice of a wider concat buffer.  dtype: UMI_F32 / UMI_F16 storage,
+ *    accumulation is always fp32.
+ *  - Input transform `tx` (nullable): one float4 per input channel {sub, scale, shift, lo};
+ *    a conv/pool/etc. consumes  max((x - sub) * scale + shift, lo)  of the stored value,
+ *    i.e. BatchNorm-apply + ReLU of the producer is fused into the consumer's load
+ *    (lo = 0 for ReLU channels, -inf for pass-through channels of a concat buffer).
+ *    Zero padding is applied AFTER the transform, as in the reference
+ *    (Conv2d(padding=1) sees zeros of the activated tensor).
+ *  - Workspaces: `*_ws_bytes()` returns the bytes the matching call needs.
+ */
+#ifndef UNETMI_H
+#define UNETMI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* umi_stream_t;          /* hipStream_t */
+
+enum { UMI_F32 = 0, UMI_F16 = 1 };
+enum { UMI_OK = 0, UMI_ERR_BADARG = -1, UMI_ERR_UNSUPPORTED = -2, UMI_ERR_WORKSPACE = -3 };
+/* umi_conv_fwd flags */
+enum { UMI_CONV_UPSAMPLE2 = 1,   /* ConvTranspose2d(k=2,s=2): tap t=(dy,dx) scatters to (2h+dy+off_h, 2w+dx+off_w) */
+       UMI_CONV_FORCE_GENERIC = 2 /* never take the MFMA fast path (used by tests to cross-check it) */ };
+
+int umi_version(void);
+const char* umi_arch(void);          /* "gfx950" */
+
+/* Re-layout of a weight tensor into the kernels' [T][K][N] packing (dtype storage):
+ *   dst[(t*Kpad + k)*Npad + n] = src[t'*st + k*sk + n*sn],  t' = flip_t ? T-1-t : t,
+ * zero for k >= K or n >= N.  Used for Conv2d OIHW weights (reference Model.py:15-20),
+ * their 180-degree-rotated transpose (dgrad) and ConvTranspose2d [Cin,Cout,2,2]
+ * (reference Model.py:56-57). */
+int umi_pack_kn(const float* src, void* dst, int T, int K, int N, long st, long sk, long sn,
+                int flip_t, int Kpad, int Npad, int dtype, umi_stream_t stream);
+
+/* Same packing for the MFMA kernels: dst[t][k/8][n][k%8] (8 consecutive k contiguous). */
+int umi_pack_kn8(const float* src, void* dst, int T, int K, int N, long st, long sk, long sn,
+                 int flip_t, int Kpad, int Npad, int dtype, umi_stream_t stream);
+
+/* Convolution forward, NHWC: replaces nn.Conv2d / F.conv2d on the hot path
+ * (reference Model.py:15-16,19-20,89; vit_seg_modeling.py:145-148,265-272,321;
+ *  vit_seg_modeling_resnet_skip.py:22-25) and, with UMI_CONV_UPSAMPLE2,
+ * nn.ConvTranspose2d(k=2,s=2) (reference Model.py:56-57,67).
+ *   y[n,ho,wo,co] = bias[co] + sum_{r,s,ci} tx(x[n,ho*stride-pad+r,wo*stride-pad+s,ci]) * wp[r*S+s][ci][co]
+ * `stat_part` (nullable) receives per-pixel-tile partial sums for BatchNorm statistics,
+ * layout [rows][2][Co] (sum, sum of squares of the *stored* y), rows = umi_conv_stat_rows().
+ * Also used for dgrad (weights packed with flip_t, pad' = R-1-pad, stride 1). */
+int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias,
+                 void* y, int ldy, float* stat_part,
+                 int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
+                 int Ho, int Wo, int off_h, int off_w, int out_H, int out_W,
+                 int in_dtype, int out_dtype, int flags, umi_stream_t stream);
+int umi_conv_stat_rows(int N, int Ho, int Wo, int Ci, int Co, int R, int S, int in_dtype, int flags);
+
+/* BatchNorm2d training statistics -> consumer transform (reference Model.py:17,21 =
+ * nn.BatchNorm2d: biased batch variance for normalisation, unbiased into running_var,
+ * momentum 0.1).  tx_out[c] = {mean, gamma*rstd, beta, 0}; running stats updated in place
+ * when non-null. */
+int umi_bn_finalize(const float* stat_part, int rows, int C, double count,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var,
+                    void* tx_out, float* rstd_out, umi_stream_t stream);
+
+/* MaxPool2d(2) of the transformed tensor (reference Model.py:36,42). Floor mode. */
+int umi_pool2_fwd(const void* x, int ldx, const void* tx, void* y, int ldy,
+                  int N, int H, int W, int C, int dtype, umi_stream_t stream);
+/* Its backward: routes dpool to the first arg-max of tx(x) in each 2x2 window (PyTorch
+ * tie rule); accumulate != 0 adds into `da` (skip-connection gradient already there). */
+int umi_pool2_bwd(const void* dpool, int lddp, const void* x, int ldx, const void* tx,
+                  void* da, int ldda, int accumulate,
+                  int N, int H, int W, int C, int dtype, umi_stream_t stream);
+
+/* BatchNorm+ReLU backward (autograd of reference Model.py:17-18,21-22).
+ *   z = tx(y) before the clamp, dz = da * [z > 0],  xhat = (y - mean) * rstd
+ *   reduce: sum_dz[c] = sum dz, sum_dzx[c] = sum dz*xhat      (d beta, d gamma)
+ *   apply : dy = gamma*rstd * (dz - sum_dz/M - xhat*sum_dzx/M)   written over `da`. */
+size_t umi_bn_bwd_ws_bytes(long M, int C);
+int umi_bn_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const void* tx,
+                      const float* rstd, float* sum_dz, float* sum_dzx,
+                      long M, int C, int dtype, void* ws, size_t ws_bytes, umi_stream_t stream);
+int umi_bn_bwd_apply(void* da, int ldda, const void* y, int ldy, const void* tx,
+                     const float* rstd, const float* sum_dz, const float* sum_dzx,
+                     long M, int C, int dtype, umi_stream_t stream);
+
+/* Weight gradient of umi_conv_fwd (autograd of the reference convs):
+ *   dW[co*s_co + ci*s_ci + t*s_t] = out_scale * sum_{n,ho,wo} txa(x[...,ci]) * txb(dy[n,ho,wo,co])
+ * fp32 output in the parameter's own layout (OIHW: s_co=Ci*R*S, s_ci=R*S, s_t=1).
+ * Deterministic: split-K partial slabs in `ws`, reduced in fixed order. */
+size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co, int R, int S, int dtype, int flags);
+int umi_conv_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, const void* txb,
+                   float* dW, long s_co, long s_ci, long s_t, float out_scale,
+                   int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
+                   int Ho, int Wo, int dtype, int flags, void* ws, size_t ws_bytes, umi_stream_t stream);
+
+/* Per-channel sum over pixels (bias gradients): out[c] = out_scale * sum_p x[p, c]. */
+size_t umi_colsum_ws_bytes(long M, int C);
+int umi_colsum(const void* x, int ldx, float* out, float out_scale, long M, int C, int dtype,
+               void* ws, size_t ws_bytes, umi_stream_t stream);
+
+/* Materialise an activation (storage + consumer transform) as NCHW fp32: the tensor a
+ * reference block returns (e.g. DoubleConv.forward, reference Model.py:25-26). */
+int umi_materialize_nchw(const void* x, int ldx, const void* tx, float* y_nchw,
+                         int N, int H, int W, int C, int dtype, umi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETMI_H */

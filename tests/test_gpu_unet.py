@@ -1,0 +1,238 @@
+"""GPU parity tests (run on the MI355X with -m gpu): HIP path vs the golden fixtures (outputs of the
+reference itself) and vs the CPU oracle on the same seeded inputs.
+
+Tolerances: fp32 mode -- logits within rtol 1e-4 (north_star), gradients 2e-3 of the tensor's scale
+(different summation order through 23 layers); fp16 mode -- stated per test.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe, ref_unet
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X: torch.cuda.is_available() is False")
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def max_err_scaled(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def test_library_loaded_in_process():
+    _need_gpu()
+    from umi import lib
+    assert lib.fn("umi_arch")() == b"gfx950"
+    maps = open("/proc/self/maps").read()
+    assert "libunetmi.so" in maps
+
+
+# ---- blocks vs reference outputs -----------------------------------------------------------
+def _load_block(g, prefix, mod, seed):
+    mod.load_state_dict(recipe.fill_state_dict(mod.state_dict(), seed=seed))
+    return mod.to(DEV)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("fp16", 6e-3)])
+def test_double_conv_block(golden_dir, dtype, tol):
+    _need_gpu()
+    import Model
+    g = np.load(os.path.join(golden_dir, "unet_blocks.npz"))
+    dc = _load_block(g, "dc", Model.DoubleConv(3, 8, compute_dtype=dtype), 1)
+    x = torch.from_numpy(g["dc_x"]).to(DEV).requires_grad_(True)
+    dc.train()
+    y = dc(x)
+    y.backward(torch.from_numpy(g["dc_gy"]).to(DEV))
+    assert max_err_scaled(y, torch.from_numpy(g["dc_train_y"])) < tol
+    assert rel_err(x.grad, torch.from_numpy(g["dc_train_gx"])) < 30 * tol
+    for k, p in dc.named_parameters():
+        assert rel_err(p.grad, torch.from_numpy(g["dc_grad." + k])) < 30 * tol, k
+    for k, b in dc.named_buffers():
+        ref = torch.from_numpy(g["dc_buf." + k])
+        if "num_batches" in k:
+            assert int(b) == int(ref)
+        else:
+            assert max_err_scaled(b, ref) < max(tol, 1e-5), k
+    dc.eval()
+    with torch.no_grad():
+        ye = dc(x.detach())
+    assert max_err_scaled(ye, torch.from_numpy(g["dc_eval_y"])) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("fp16", 6e-3)])
+def test_down_up_out_blocks(golden_dir, dtype, tol):
+    _need_gpu()
+    import Model
+    g = np.load(os.path.join(golden_dir, "unet_blocks.npz"))
+    dn = _load_block(g, "down", Model.Down(8, 16, compute_dtype=dtype), 2).train()
+    x = torch.from_numpy(g["down_x"]).to(DEV).requires_grad_(True)
+    y = dn(x)
+    y.backward(torch.from_numpy(g["down_gy"]).to(DEV))
+    assert max_err_scaled(y, torch.from_numpy(g["down_y"])) < tol
+    assert rel_err(x.grad, torch.from_numpy(g["down_gx"])) < 30 * tol
+    for k, p in dn.named_parameters():
+        assert rel_err(p.grad, torch.from_numpy(g["down_grad." + k])) < 30 * tol, k
+
+    up = _load_block(g, "up", Model.Up(16, 8, compute_dtype=dtype), 3).train()
+    x1 = torch.from_numpy(g["up_x1"]).to(DEV).requires_grad_(True)
+    x2 = torch.from_numpy(g["up_x2"]).to(DEV).requires_grad_(True)
+    y = up(x1, x2)                                   # odd skip size: exercises the F.pad path
+    y.backward(torch.from_numpy(g["up_gy"]).to(DEV))
+    assert max_err_scaled(y, torch.from_numpy(g["up_y"])) < tol
+    assert rel_err(x1.grad, torch.from_numpy(g["up_gx1"])) < 30 * tol
+    assert rel_err(x2.grad, torch.from_numpy(g["up_gx2"])) < 30 * tol
+    for k, p in up.named_parameters():
+        assert rel_err(p.grad, torch.from_numpy(g["up_grad." + k])) < 30 * tol, k
+
+    oc = _load_block(g, "outc", Model.OutConv(8, 3, compute_dtype=dtype), 4)
+    y = oc(torch.from_numpy(g["outc_x"]).to(DEV))
+    assert max_err_scaled(y, torch.from_numpy(g["outc_y"])) < tol
+
+
+# ---- whole network -------------------------------------------------------------------------------
+def _oracle_run(g, steps):
+    cin, ncls, feat = int(g["cin"]), int(g["ncls"]), int(g["feat"])
+    B, H, W, seed = int(g["B"]), int(g["H"]), int(g["W"]), int(g["seed"])
+    m = ref_unet.RefUNet(cin, ncls, feat, False)
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed))
+    x, lab = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
+    return m, x, lab
+
+
+@pytest.mark.parametrize("name", ["unet_1_2_8", "unet_3_4_8"])
+def test_unet_fp32_parity(golden_dir, name):
+    """fp32 HIP path: logits rtol 1e-4 vs the REFERENCE's logits, argmax identical off near-ties,
+    loss/grads/3 SGD steps/eval-mode logits vs the oracle."""
+    _need_gpu()
+    import Model
+    import loss as L
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    ref, x, lab = _oracle_run(g, 3)
+    ncls = int(g["ncls"])
+    L.CLASS_NUMBER = ncls
+    m = Model.UNet(int(g["cin"]), ncls, int(g["feat"]), False, compute_dtype="fp32")
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).train()
+    ref.train()
+    xd, labd = x.to(DEV), lab.to(DEV)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for step in range(3):
+        logits = m(xd)
+        loss = L.calc_loss(logits, labd, loss_type="dice_bce_mc")
+        opt.zero_grad()
+        loss.backward()
+        rlogits = ref(x)
+        rloss = ref_unet.dice_bce_mc(rlogits, lab, ncls)
+        ropt.zero_grad()
+        rloss.backward()
+        if step == 0:
+            gl = torch.from_numpy(g["logits"])
+            np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=1e-4, atol=1e-4 * gl.abs().max().item())
+            top2 = torch.topk(gl, 2, dim=1).values
+            safe = (top2[:, 0] - top2[:, 1]) > 1e-4 * gl.abs().max()
+            am = logits.argmax(1).cpu()
+            assert (am == torch.from_numpy(g["argmax"]).long())[safe].all()
+            assert abs(loss.item() - float(g["loss0"])) < 1e-5
+        assert abs(loss.item() - float(g[f"loss{step}"])) < 5e-5, step
+        for (k, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters()):
+            assert rel_err(p.grad, rp.grad) < (2e-3 if step == 0 else 2e-2), (step, k)
+        opt.step()
+        ropt.step()
+    for k, v in m.state_dict().items():
+        rv = ref.state_dict()[k]
+        if "num_batches" in k:
+            assert int(v) == int(rv) == 3
+        else:
+            assert rel_err(v.float(), rv.float()) < 1e-3, k
+    m.eval()
+    with torch.no_grad():
+        ev = m(xd)
+    np.testing.assert_allclose(ev.cpu().numpy(), g["eval_logits"], rtol=2e-3,
+                               atol=2e-3 * float(np.abs(g["eval_logits"]).max()))
+
+
+@pytest.mark.parametrize("name", ["unet_1_2_8", "unet_3_4_8"])
+def test_unet_fp16_close_to_oracle(golden_dir, name):
+    """fp16-storage path (the benchmarked one): logits within 2e-2 of the logit scale of the fp32
+    reference, loss within 2e-3, gradients within 5% relative L2 (fp16 activations through 23 layers)."""
+    _need_gpu()
+    import Model
+    import loss as L
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    ref, x, lab = _oracle_run(g, 1)
+    ncls = int(g["ncls"])
+    L.CLASS_NUMBER = ncls
+    m = Model.UNet(int(g["cin"]), ncls, int(g["feat"]), False, compute_dtype="fp16")
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).train()
+    logits = m(x.to(DEV))
+    loss = L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc")
+    loss.backward()
+    assert logits.dtype == torch.float32
+    assert max_err_scaled(logits, torch.from_numpy(g["logits"])) < 2e-2
+    assert abs(loss.item() - float(g["loss0"])) < 2e-3
+    ref.train()
+    rl = ref_unet.dice_bce_mc(ref(x), lab, ncls)
+    rl.backward()
+    worst = max(rel_err(p.grad, rp.grad) for (_, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters()))
+    assert worst < 5e-2, worst
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_unet_config1_scale_fp32(golden_dir):
+    """Config 1 shape (UNet(1,2,64), B=2, 256x256): logits signature + argmax mask vs the reference."""
+    _need_gpu()
+    import Model
+    import loss as L
+    from tests.test_oracle_golden import sig
+    g = np.load(os.path.join(golden_dir, "unet_c1.npz"))
+    L.CLASS_NUMBER = 2
+    m = Model.UNet(1, 2, 64, False, compute_dtype="fp32")
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=int(g["seed"])))
+    m.to(DEV).train()
+    x, lab = recipe.synthetic_batch(2, 1, 256, 256, 2, seed=int(g["seed"]))
+    logits = m(x.to(DEV))
+    loss = L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc")
+    loss.backward()
+    s = sig(logits.cpu())
+    np.testing.assert_allclose(s[[0, 2]], g["logits_sig"][[0, 2]], rtol=1e-4)
+    np.testing.assert_allclose(s[3:], g["logits_sig"][3:], rtol=1e-4, atol=1e-4 * s[0] / 300)
+    assert abs(loss.item() - float(g["loss0"])) < 1e-5
+    am = logits.argmax(1).cpu().numpy().astype(np.uint8)
+    mism = int((am != g["argmax"]).sum())
+    # near-tie pixels (|top-2 margin| below the 1e-4 tolerance band) may flip; count and bound them
+    top2 = torch.topk(logits.detach(), 2, dim=1).values
+    near = int(((top2[:, 0] - top2[:, 1]) < 1e-4 * logits.abs().max()).sum())
+    assert mism <= near, (mism, near)
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.double().norm().item(), g["grad_sig." + k][0], rtol=5e-3)
+
+
+def test_forward_is_deterministic():
+    _need_gpu()
+    import Model
+    torch.manual_seed(1)
+    m = Model.UNet(1, 2, 8, compute_dtype="fp16").to(DEV).train()
+    x = torch.randn(2, 1, 64, 64, device=DEV)
+    outs = []
+    for _ in range(2):
+        m.zero_grad()
+        y = m(x)
+        y.square().mean().backward()
+        outs.append((y.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))

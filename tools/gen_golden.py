@@ -142,10 +142,12 @@ def gen_unet_case(Model, loss_mod, name, cin, ncls, feat, B, H, W, seed, full_lo
     torch.manual_seed(0)
     loss_mod.CLASS_NUMBER = ncls
     m = Model.UNet(cin, ncls, feat, False)
+    out = dict(cin=cin, ncls=ncls, feat=feat, B=B, H=H, W=W, seed=seed)
+    for k, v in m.state_dict().items():          # reference init under torch.manual_seed(0)
+        out["init_sig." + k] = sig(v.float())
     m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed))
     x, lab = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
-    out = dict(cin=cin, ncls=ncls, feat=feat, B=B, H=H, W=W, seed=seed)
     m.train()
     for step in range(steps):
         logits = m(x)

@@ -1,0 +1,261 @@
+"""MI355X-native U-Net: drop-in for the reference `Model.py` (caki35/UNet-Torch).
+
+Same class names, constructor signatures and `state_dict` keys as the reference
+(`DoubleConv` Model.py:7-26, `Down` :29-47, `Up` :50-83, `OutConv` :86-92, `UNet` :95-169),
+so `from Model import UNet`, `load_state_dict(torch.load('best.pt'))` and the reference
+`Trainer` work unchanged.  The arithmetic does not go through torch.nn: `forward` builds a
+tape of libunetmi HIP kernels (umi/graph.py) -- NHWC activations, BatchNorm statistics in
+the conv epilogue, BN-apply+ReLU fused into the consumer's load, zero-copy skip
+concatenation -- and a hand-written backward pass.  The nn.Conv2d / nn.BatchNorm2d children
+only own parameters and buffers.
+
+Build-specific, keyword-only extras (never positional, so reference call sites are
+unaffected): `compute_dtype` = "fp16" (fp16 storage + fp32 accumulate, loss-scaled
+gradients; default, env UMI_COMPUTE_DTYPE) or "fp32" (parity mode).
+
+There is no CPU path here: inputs must live on the MI355X ("cuda" in PyTorch-ROCm naming).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from umi import graph as G
+
+
+def _resolve_dtype(compute_dtype):
+    name = compute_dtype or os.environ.get("UMI_COMPUTE_DTYPE", "fp16")
+    if isinstance(name, torch.dtype):
+        return name
+    table = {"fp16": torch.float16, "float16": torch.float16, "half": torch.float16,
+             "fp32": torch.float32, "float32": torch.float32}
+    if name not in table:
+        raise ValueError(f"compute_dtype must be fp16 or fp32, got {name!r}")
+    return table[name]
+
+
+class _TapeFunction(torch.autograd.Function):
+    """Bridges a libunetmi tape into torch.autograd: one node for the whole block/network."""
+
+    @staticmethod
+    def forward(ctx, run, n_inputs, *tensors):
+        inputs, params = tensors[:n_inputs], tensors[n_inputs:]
+        record = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+        tape, in_acts, out_act, out = run(record, [bool(t.requires_grad) for t in inputs])
+        ctx.tape, ctx.in_acts, ctx.out_act, ctx.params, ctx.n_inputs = tape, in_acts, out_act, params, n_inputs
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        tape = ctx.tape
+        if tape is None or not tape.record:
+            raise RuntimeError("backward called on a tape that was built without gradient recording")
+        tape.seed_grad_nchw(ctx.out_act, gout)
+        tape.backward()
+        gin = [tape.input_grad_nchw(a) if need else None
+               for a, need in zip(ctx.in_acts, ctx.needs_input_grad[2:2 + ctx.n_inputs])]
+        gpar = []
+        for p, need in zip(ctx.params, ctx.needs_input_grad[2 + ctx.n_inputs:]):
+            g = tape.param_grads.get(id(p))
+            gpar.append(g[1].to(p.dtype) if (g is not None and need) else None)
+        ctx.tape = None
+        return (None, None, *gin, *gpar)
+
+
+def _run_tape(module, inputs, build):
+    """Run `build(tape, *input_acts) -> Act` for `module`; returns an NCHW fp32 tensor."""
+    params = [p for p in module.parameters()]
+    dtype = module._umi_dtype()
+    N, _, H, W = inputs[0].shape
+
+    def run(record, in_needs):
+        tape = G.Tape(dtype, training=module.training, record=record,
+                      loss_scale=G.default_loss_scale(dtype, N * H * W),
+                      grad_sink=getattr(module, "_umi_grad_sink", None) if record else None)
+        acts = [tape.input_nchw(x, needs_grad=need) for x, need in zip(inputs, in_needs)]
+        out_act = build(tape, *acts)
+        if out_act.tx is None and out_act.raw.dtype == torch.float32:
+            out = tape.output_nchw_plain(out_act)
+        else:
+            from umi import ops
+            out = ops.materialize_nchw(out_act.raw, out_act.tx)
+        return tape, acts, out_act, out
+
+    return _TapeFunction.apply(run, len(inputs), *inputs, *params)
+
+
+class _UmiModule(nn.Module):
+    _compute_dtype = None
+
+    def _umi_dtype(self):
+        return _resolve_dtype(self._compute_dtype)
+
+
+# ---- tape builders shared by the blocks and the full network -----------------------------------
+def _build_double_conv(t, a, dc, out=None):
+    seq = dc.double_conv
+    y1 = t.conv_bn(a, seq[0].weight, seq[1])
+    return t.conv_bn(y1, seq[3].weight, seq[4], out=out)
+
+
+def _check_dropout(mod, flag):
+    if flag and mod.training:
+        raise NotImplementedError(
+            "dropout=True in training mode is not implemented by the HIP path yet (reference default is "
+            "dropout=False, Model.py:96); eval mode is supported")
+
+
+def _build_down(t, a, down, out=None):
+    _check_dropout(down, down.dropout)
+    return _build_double_conv(t, t.pool2(a), down.maxpool_conv[-1], out=out)
+
+
+def _build_up(t, x1, skip, cat, up):
+    """`skip` already lives in cat[..., :C]; the transposed conv fills cat[..., C:]."""
+    _check_dropout(up, up.dropout_flag)
+    C = skip.shape[3]
+    u = t.conv_transpose2x2(x1, up.up.weight, up.up.bias, cat[..., C:])
+    return _build_double_conv(t, t.concat(cat, [skip, u]), up.conv)
+
+
+class DoubleConv(_UmiModule):
+    """(convolution => [BN] => ReLU) * 2 -- reference Model.py:7-26."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, *, compute_dtype=None):
+        super().__init__()
+        mid_channels = mid_channels or out_channels
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(mid_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True))
+        self._compute_dtype = compute_dtype
+
+    def forward(self, x):
+        return _run_tape(self, [x], lambda t, a: _build_double_conv(t, a, self))
+
+
+class Down(_UmiModule):
+    """MaxPool2d(2) [-> Dropout] -> DoubleConv -- reference Model.py:29-47."""
+
+    def __init__(self, in_channels, out_channels, dropout=False, dropout_p=0.5, *, compute_dtype=None):
+        super().__init__()
+        layers = [nn.MaxPool2d(2)]
+        if dropout:
+            layers.append(nn.Dropout(p=dropout_p))
+        layers.append(DoubleConv(in_channels, out_channels))
+        self.maxpool_conv = nn.Sequential(*layers)
+        self.dropout = dropout
+        self._compute_dtype = compute_dtype
+
+    def forward(self, x):
+        return _run_tape(self, [x], lambda t, a: _build_down(t, a, self))
+
+
+class Up(_UmiModule):
+    """ConvTranspose2d(k2,s2) -> pad -> cat([skip, up]) [-> Dropout] -> DoubleConv -- Model.py:50-83."""
+
+    def __init__(self, in_channels, out_channels, dropout_flag=False, dropout_p=0.5, *, compute_dtype=None):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+        self.conv = DoubleConv(in_channels, out_channels)
+        self.dropout_flag = dropout_flag
+        if dropout_flag:
+            self.dropout = nn.Dropout(p=dropout_p)
+        self._compute_dtype = compute_dtype
+
+    def forward(self, x1, x2):
+        def build(t, a1, a2):
+            N, H, W, C = a2.shape
+            cat = t.alloc(N, H, W, C + self.up.out_channels, device=a2.raw.device)
+            cat[..., :C].copy_(a2.raw)
+            a2.raw = cat[..., :C]
+            return _build_up(t, a1, a2, cat, self)
+        return _run_tape(self, [x1, x2], build)
+
+
+class OutConv(_UmiModule):
+    """1x1 conv + bias -- reference Model.py:86-92."""
+
+    def __init__(self, in_channels, out_channels, *, compute_dtype=None):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self._compute_dtype = compute_dtype
+
+    def forward(self, x):
+        return _run_tape(self, [x], lambda t, a: t.conv_bias(a, self.conv.weight, self.conv.bias,
+                                                             out_dtype=torch.float32))
+
+
+class UNet(_UmiModule):
+    """4-down/4-up U-Net -- reference Model.py:95-169 (same positional ctor arguments)."""
+
+    def __init__(self, n_channels, n_classes, initial_feature_map=64, usa_cuda=True, dropout=False,
+                 dropout_p=0.5, *, compute_dtype=None):
+        super().__init__()
+        self.usa_cuda = usa_cuda
+        self.n_channels = {-2: 3, -1: 1}.get(n_channels, n_channels)
+        self.n_classes = n_classes
+        self.initial_feature_map = f = initial_feature_map
+        self.dropout = dropout
+        self.dropout_p = dropout_p
+        self._compute_dtype = compute_dtype
+
+        # Built stage by stage with `.apply(weights_init)` right after each one, like the reference
+        # (Model.py:111-140), so the RNG stream -- and therefore `torch.manual_seed(s); UNet(...)` --
+        # yields the same initial weights: kaiming-normal on nn.Conv2d only (ConvTranspose2d keeps
+        # torch's default init).
+        def stage(mod):
+            mod.apply(self.weights_init)
+            return mod
+        self.inc = stage(DoubleConv(self.n_channels, f))
+        self.down1 = stage(Down(f, f * 2, dropout, dropout_p))
+        self.down2 = stage(Down(f * 2, f * 4, dropout, dropout_p))
+        self.down3 = stage(Down(f * 4, f * 8, dropout, dropout_p))
+        self.down4 = stage(Down(f * 8, f * 16, dropout, dropout_p))
+        self.up1 = stage(Up(f * 16, f * 8, dropout, dropout_p))
+        self.up2 = stage(Up(f * 8, f * 4, dropout, dropout_p))
+        self.up3 = stage(Up(f * 4, f * 2, dropout, dropout_p))
+        self.up4 = stage(Up(f * 2, f, dropout, dropout_p))
+        self.outc = stage(OutConv(f, n_classes))
+
+    def weights_init(self, m):
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.n_channels:
+            raise ValueError(f"expected input [B,{self.n_channels},H,W], got {tuple(x.shape)}")
+
+        def build(t, a):
+            N, H, W, _ = a.shape
+            f, dev = self.initial_feature_map, a.raw.device
+            skips = []
+            cur = a
+            stages = [self.inc, self.down1, self.down2, self.down3, self.down4]
+            for lvl, st in enumerate(stages):
+                C = f * 2 ** lvl
+                h, w = (cur.shape[1], cur.shape[2]) if lvl == 0 else (cur.shape[1] // 2, cur.shape[2] // 2)
+                if lvl < 4:          # encoder output doubles as the lower half of the decoder's concat buffer
+                    cat = t.alloc(N, h, w, 2 * C, device=dev)
+                    out = cat[..., :C]
+                else:
+                    cat, out = None, None
+                cur = _build_double_conv(t, cur, st, out=out) if lvl == 0 else _build_down(t, cur, st, out=out)
+                skips.append((cur, cat))
+            y = cur
+            for i, up in enumerate([self.up1, self.up2, self.up3, self.up4]):
+                skip, cat = skips[3 - i]
+                y = _build_up(t, y, skip, cat, up)
+            return t.conv_bias(y, self.outc.conv.weight, self.outc.conv.bias, out_dtype=torch.float32)
+
+        return _run_tape(self, [x], build)
+
+    def use_checkpointing(self):
+        # Dead code in the reference (Model.py:155-165: torch.utils.checkpoint is a module, the call
+        # raises).  Saved activations are raw fp16 conv outputs here (~5.5 GB at B=16, 512^2 on a
+        # 288 GB part), so activation checkpointing is unnecessary.
+        raise NotImplementedError("use_checkpointing is broken in the reference and unnecessary here")

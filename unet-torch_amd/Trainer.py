@@ -1,0 +1,207 @@
+"""Training loop: drop-in for the reference `Trainer.py` on the hot-path model types.
+
+Keeps `Trainer(model, model_type, dtype, device, output_save_dir, dataloaders, batch_size,
+optimizer, patience, num_epochs, loss_function, accuracy_metric, lr_scheduler=None,
+start_epoch=1)` and `.train()` (reference Trainer.py:12-50, :113-129), and the behaviour of
+`singe_train` (Trainer.py:663-829): per-batch order  to(device)/type -> forward -> calc_loss ->
+zero_grad -> backward -> step -> poly-LR with the pre-increment `iter_num` (:719-726); model
+selection on `val_score < best_val_score` (:752); early stop on `counter > patience` (:768);
+files `logs.txt`, `models/{epochN,best,last_epoch}.pt`, `total.png`.
+
+Differences, all host-side: the step body is factored into `train_step` (reused by the
+data-parallel runner, umi/ddp.py) and the running loss is accumulated on the device and read
+back once per epoch instead of a `.item()` sync every step (Trainer.py:727).  The other epoch
+loops of the reference (multi-task, CLTR, Topo losses) are out of scope and raise.
+"""
+import copy
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+from tqdm import tqdm
+
+from loss import calc_loss
+
+_SINGLE = ('single', 'TransUnet', 'regression', 'regression_t', 'attention')
+_TOPO = ('TopoCount', 'TopoCount2', 'TopoLoss', 'TopoLoss2', 'MyTopoLoss1', 'MyTopoLoss2', 'MyTopoLossGraph',
+         'MyTopoLossVR')
+_OTHER = ('multi_task', 'multi_task_reg', 'multi_task_regTU', 'CLTR')
+
+
+class Trainer():
+    def __init__(self, model, model_type, dtype, device, output_save_dir, dataloaders, batch_size, optimizer,
+                 patience, num_epochs, loss_function, accuracy_metric, lr_scheduler=None, start_epoch=1):
+        self.model = model
+        self.model_type = model_type
+        self.dtype = dtype
+        self.device = device
+        self.output_save_dir = output_save_dir
+        self.dataloader = dataloaders
+        self.batch_size = batch_size
+        self.optimizer = optimizer
+        self.patience = patience
+        self.num_epochs = num_epochs
+        self.loss_function = loss_function
+        self.accuracy_metric = accuracy_metric
+        self.lr_scheduler = lr_scheduler
+        self.start_epoch = start_epoch
+
+        self.phases = ["train", "val"]
+        self.iter_num = 0
+        self.base_lr = self.optimizer.param_groups[-1]['lr']
+        self.max_iterations = self.num_epochs * len(self.dataloader['train'])
+        self.best_loss = 1e15
+        self.best_val_score = 0 if accuracy_metric in ('dice_score', 'dice_score_mc') else 1e15
+        self.best_model = []
+        self.early_stop_counter = 0
+        self.train_loss_list, self.val_loss_list, self.val_score_list = [], [], []
+        self.grad_sync = None         # optional callable run between backward and optimizer.step (DDP)
+
+        self.save_dir_model = os.path.join(self.output_save_dir, 'models/')
+        os.makedirs(self.save_dir_model, exist_ok=True)
+
+    # ------------------------------------------------------------------------------------
+    def train(self):
+        if self.model_type in _SINGLE:
+            if self.loss_function in _TOPO:
+                raise NotImplementedError("Topo-loss warm-up loop (reference singe_train_wup) is out of scope")
+            return self.singe_train()
+        if self.model_type in _OTHER:
+            raise NotImplementedError(f'model_type "{self.model_type}" (multi-task / CLTR loops) is out of scope')
+        raise ValueError('Invalid model_type "%s"' % self.model_type)
+
+    # ------------------------------------------------------------------------------------
+    def _to_device(self, inputs, labels):
+        return inputs.to(self.device).type(self.dtype), labels.to(self.device).type(self.dtype)
+
+    def _forward_loss(self, inputs, labels):
+        out = self.model(inputs)
+        if self.model_type in ('regression', 'regression_t'):
+            out = F.relu(out)
+        return out, calc_loss(out, labels, loss_type=self.loss_function)
+
+    def train_step(self, inputs, labels):
+        """One optimisation step (reference Trainer.py:700-726).  Returns the detached loss tensor."""
+        inputs, labels = self._to_device(inputs, labels)
+        with torch.set_grad_enabled(True):
+            _, loss = self._forward_loss(inputs, labels)
+            self.optimizer.zero_grad()
+            loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync()
+            self.optimizer.step()
+        if self.lr_scheduler:
+            lr_ = self.base_lr * (1.0 - self.iter_num / self.max_iterations) ** 0.9
+            for group in self.optimizer.param_groups:
+                group['lr'] = lr_
+        self.iter_num += 1
+        return loss.detach()
+
+    def eval_step(self, inputs, labels):
+        inputs, labels = self._to_device(inputs, labels)
+        with torch.no_grad():
+            out, loss = self._forward_loss(inputs, labels)
+            score = calc_loss(out, labels, loss_type=self.accuracy_metric)
+        return loss.detach(), score.detach()
+
+    # ------------------------------------------------------------------------------------
+    def singe_train(self):
+        os.makedirs(self.output_save_dir, exist_ok=True)
+        log = open(os.path.join(self.output_save_dir, "logs.txt"), 'a')
+
+        def say(msg, echo=True):
+            if echo:
+                print(msg)
+            log.write(msg + "\n")
+
+        use_cuda = torch.cuda.is_available()
+        total_mem = f'{torch.cuda.get_device_properties(0).total_memory / 1E9 if use_cuda else 0:.3g}G'
+        total_time = 0.0
+        for epoch in range(self.start_epoch, self.num_epochs + 1):
+            log.write('Epoch {}/{}\n'.format(epoch, self.num_epochs) + '-' * 10 + "\n")
+            since = time.time()
+            for phase in self.phases:
+                train = phase == 'train'
+                if train:
+                    for group in self.optimizer.param_groups:
+                        print("LR", group['lr'])
+                        log.write(f"LR {group['lr']}\n")
+                    since = time.time()
+                self.model.train(train)
+
+                loss_sum, score_sum, steps = None, None, 0
+                with tqdm(self.dataloader[phase], unit="batch") as bar:
+                    for inputs, labels in bar:
+                        bar.set_description(f"Epoch {epoch}")
+                        steps += 1
+                        if train:
+                            loss = self.train_step(inputs, labels)
+                        else:
+                            loss, score = self.eval_step(inputs, labels)
+                            score_sum = score if score_sum is None else score_sum + score
+                        loss_sum = loss if loss_sum is None else loss_sum + loss
+                        if steps % 50 == 0 or not use_cuda:     # avoid a device sync on every step
+                            mem = f'{torch.cuda.memory_reserved() / 1E9 if use_cuda else 0:.3g}G/' + total_mem
+                            bar.set_postfix(loss=float(loss_sum) / steps, memory=mem)
+                epoch_loss = float(loss_sum) / steps
+
+                if train:
+                    elapsed = time.time() - since
+                    say('Training Time for this epoch: {:.0f}m {:.0f}s\n'.format(elapsed // 60, elapsed % 60))
+                    self.train_loss_list.append(epoch_loss)
+                    say("Train loss on epoch %i: %f" % (epoch, epoch_loss))
+                    total_time += elapsed
+                    self.meanTimePerEpoch = total_time / epoch
+                    say('Curent mean training time per epoch: {:.0f}m {:.0f}s\n'.format(
+                        self.meanTimePerEpoch // 60, self.meanTimePerEpoch % 60))
+                    torch.save(self.model.state_dict(), os.path.join(self.save_dir_model, 'last_epoch.pt'))
+                    continue
+
+                val_score = float(score_sum) / steps
+                self.val_loss_list.append(epoch_loss)
+                self.val_score_list.append(val_score)
+                say("Val loss on epoch %i: %f" % (epoch, epoch_loss))
+                say("Val score on epoch %i: %f" % (epoch, val_score))
+                if val_score < self.best_val_score:
+                    self.early_stop_counter = 0
+                    self.best_val_score = val_score
+                    self.best_loss = epoch_loss
+                    say("saving best model")
+                    self.best_model = copy.deepcopy(self.model.state_dict())
+                    torch.save(self.best_model, os.path.join(self.save_dir_model, 'epoch{}.pt'.format(epoch)))
+                    torch.save(self.best_model, os.path.join(self.save_dir_model, 'best.pt'))
+                else:
+                    self.early_stop_counter += 1
+                if self.early_stop_counter > self.patience:
+                    say("Early stopping")
+                    return self._finish(log, say)
+
+            elapsed = time.time() - since
+            say('{:.0f}m {:.0f}s\n'.format(elapsed // 60, elapsed % 60))
+        return self._finish(log, say)
+
+    def _finish(self, log, say):
+        say('Best val loss: {:4f}'.format(self.best_loss))
+        say('Best val score: {:4f}'.format(self.best_val_score))
+        log.close()
+        self.plot_loss_functions('total')
+        if self.best_model:
+            self.model.load_state_dict(self.best_model)     # load best model weights
+        return self.model
+
+    def plot_loss_functions(self, name):
+        """Train/val loss curves -> <output_save_dir>/<name>.png (reference Trainer.py:52-111)."""
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        fig, ax = plt.subplots(figsize=(8, 5))
+        ep = range(1, len(self.train_loss_list) + 1)
+        ax.plot(ep, self.train_loss_list, label='train loss')
+        if self.val_loss_list:
+            ax.plot(range(1, len(self.val_loss_list) + 1), self.val_loss_list, label='validation loss')
+        ax.set_xlabel('epoch')
+        ax.set_ylabel('loss')
+        ax.legend()
+        fig.savefig(os.path.join(self.output_save_dir, name + '.png'))
+        plt.close(fig)

@@ -1,0 +1,68 @@
+// C-ABI dispatch layer of libunetmi: validates arguments and picks the MFMA fast path or the
+// generic kernel.  See include/unetmi.h for the contract of every entry point.
+#include "common.h"
+
+// generic_kernels.hip
+int umi_conv_fwd_generic(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy,
+                         float* stat_part, int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
+                         int Ho, int Wo, int off_h, int off_w, int out_H, int out_W, int in_dtype, int out_dtype,
+                         int flags, hipStream_t s);
+size_t umi_conv_wgrad_generic_ws_bytes(int N, int Ho, int Wo, int Ci, int Co, int R, int S);
+int umi_conv_wgrad_generic(const void* x, int ldx, const void* txa, const void* dy, int lddy, const void* txb, float* dW,
+                           long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, int R,
+                           int S, int stride, int pad, int Ho, int Wo, int dtype, void* ws, size_t ws_bytes,
+                           hipStream_t st);
+// conv_mfma.hip
+bool umi_conv3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
+                         int ldx, int ldy, int in_dtype, int out_dtype, int flags, const float* bias);
+int umi_conv3x3_mfma_stat_rows(int N, int Ho, int Wo, int Co);
+int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
+                     int N, int H, int W, int Ci, int Co, hipStream_t s);
+bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
+                          int ldx, int lddy, int dtype, int flags, const void* txb);
+size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co);
+int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co,
+                      long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws,
+                      size_t ws_bytes, hipStream_t s);
+
+extern "C" int umi_version(void) { return 1; }
+extern "C" const char* umi_arch(void) { return "gfx950"; }
+
+extern "C" int umi_conv_stat_rows(int N, int Ho, int Wo, int Ci, int Co, int R, int S, int in_dtype, int flags) {
+    // The MFMA path (when taken) never needs more rows than the generic one.
+    (void)Ci; (void)Co; (void)R; (void)S; (void)in_dtype; (void)flags;
+    return umi_cdiv((long)N * Ho * Wo, 64);
+}
+
+extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy,
+                            float* stat_part, int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
+                            int Ho, int Wo, int off_h, int off_w, int out_H, int out_W, int in_dtype, int out_dtype,
+                            int flags, umi_stream_t stream) {
+    if (!x || !wp || !y || N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
+        Ho <= 0 || Wo <= 0 || ldx < Ci || ldy < Co || out_H <= 0 || out_W <= 0)
+        return UMI_ERR_BADARG;
+    if (!(flags & UMI_CONV_UPSAMPLE2)) {
+        if (Ho != (H + 2 * pad - R) / stride + 1 || Wo != (W + 2 * pad - S) / stride + 1) return UMI_ERR_BADARG;
+        if (out_H != Ho || out_W != Wo || off_h || off_w) return UMI_ERR_BADARG;
+    } else {
+        if (Ho != H || Wo != W) return UMI_ERR_BADARG;
+    }
+    return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
+                                off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);
+}
+
+extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co, int R, int S, int dtype, int flags) {
+    (void)dtype; (void)flags;
+    return umi_conv_wgrad_generic_ws_bytes(N, Ho, Wo, Ci, Co, R, S);
+}
+
+extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, const void* txb,
+                              float* dW, long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci,
+                              int Co, int R, int S, int stride, int pad, int Ho, int Wo, int dtype, int flags, void* ws,
+                              size_t ws_bytes, umi_stream_t stream) {
+    if (!x || !dy || !dW || !ws || N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || ldx < Ci || lddy < Co)
+        return UMI_ERR_BADARG;
+    (void)flags;
+    return umi_conv_wgrad_generic(x, ldx, txa, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S,
+                                  stride, pad, Ho, Wo, dtype, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,718 @@
+// Generic (any shape / stride / channel count) HIP kernels of libunetmi: LDS-tiled fp32-accumulate
+// VALU kernels templated on the storage type.  They are the fp32 parity path and the
+// fallback for shapes the MFMA kernels do not take; written for gfx950 (64-wide waves,
+// 256-thread workgroups = 4 waves, float4 LDS reads).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+template <typename T, bool K8>
+__global__ void pack_kn_kernel(const float* __restrict__ src, T* __restrict__ dst, int Tn, int K, int N,
+                               long st, long sk, long sn, int flip_t, int Kpad, int Npad) {
+    long total = (long)Tn * Kpad * Npad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int n, k, t;
+        if (K8) {       // dst[t][k/8][n][k%8]
+            int k8 = (int)(i & 7);
+            long r = i >> 3;
+            n = (int)(r % Npad); r /= Npad;
+            int kb = (int)(r % (Kpad / 8));
+            t = (int)(r / (Kpad / 8));
+            k = kb * 8 + k8;
+        } else {        // dst[t][k][n]
+            n = (int)(i % Npad);
+            long r = i / Npad;
+            k = (int)(r % Kpad);
+            t = (int)(r / Kpad);
+        }
+        float v = 0.f;
+        if (k < K && n < N) {
+            int ts = flip_t ? (Tn - 1 - t) : t;
+            v = src[ts * st + k * sk + n * sn];
+        }
+        dst[i] = (T)v;
+    }
+}
+
+static int pack_impl(const float* src, void* dst, int T, int K, int N, long st, long sk, long sn, int flip_t,
+                     int Kpad, int Npad, int dtype, bool k8, hipStream_t s) {
+    if (T <= 0 || K <= 0 || N <= 0 || Kpad < K || Npad < N) return UMI_ERR_BADARG;
+    if (k8 && (Kpad % 8)) return UMI_ERR_BADARG;
+    long total = (long)T * Kpad * Npad;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (dtype == UMI_F32) {
+        if (k8) hipLaunchKernelGGL((pack_kn_kernel<float, true>), dim3(grid), dim3(256), 0, s, src, (float*)dst, T, K, N, st, sk, sn, flip_t, Kpad, Npad);
+        else    hipLaunchKernelGGL((pack_kn_kernel<float, false>), dim3(grid), dim3(256), 0, s, src, (float*)dst, T, K, N, st, sk, sn, flip_t, Kpad, Npad);
+    } else if (dtype == UMI_F16) {
+        if (k8) hipLaunchKernelGGL((pack_kn_kernel<half_t, true>), dim3(grid), dim3(256), 0, s, src, (half_t*)dst, T, K, N, st, sk, sn, flip_t, Kpad, Npad);
+        else    hipLaunchKernelGGL((pack_kn_kernel<half_t, false>), dim3(grid), dim3(256), 0, s, src, (half_t*)dst, T, K, N, st, sk, sn, flip_t, Kpad, Npad);
+    } else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_pack_kn(const float* src, void* dst, int T, int K, int N, long st, long sk, long sn,
+                           int flip_t, int Kpad, int Npad, int dtype, umi_stream_t stream) {
+    return pack_impl(src, dst, T, K, N, st, sk, sn, flip_t, Kpad, Npad, dtype, false, (hipStream_t)stream);
+}
+extern "C" int umi_pack_kn8(const float* src, void* dst, int T, int K, int N, long st, long sk, long sn,
+                            int flip_t, int Kpad, int Npad, int dtype, umi_stream_t stream) {
+    return pack_impl(src, dst, T, K, N, st, sk, sn, flip_t, Kpad, Npad, dtype, true, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// generic convolution forward (implicit GEMM: 64 output pixels x 64 output channels per block)
+// ------------------------------------------------------------------------------------------
+constexpr int GBP = 64, GBC = 64, GBK = 16;
+
+template <typename TI, typename TO, bool UPS>
+__global__ __launch_bounds__(256) void conv_generic_kernel(
+    const TI* __restrict__ x, int ldx, const float4* __restrict__ tx, const TI* __restrict__ wp,
+    const float* __restrict__ bias, TO* __restrict__ y, int ldy, float* __restrict__ part,
+    int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
+    int off_h, int off_w, int out_H, int out_W) {
+    __shared__ __attribute__((aligned(16))) float As[GBK][GBP + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK][GBC + 4];
+    __shared__ float red[2][16][GBC];
+
+    const int tid = threadIdx.x;
+    const int txi = tid & 15, tyi = tid >> 4;
+    const long P = (long)N * Ho * Wo;
+    const long p0 = (long)blockIdx.x * GBP;
+    const int c0 = blockIdx.y * GBC;
+
+    // A-tile loader: this thread stages 4 consecutive ci of one pixel
+    const int lp = tid >> 2, lk = (tid & 3) * 4;
+    const long pg = p0 + lp;
+    const bool pv = pg < P;
+    int n = 0, ho = 0, wo = 0;
+    if (pv) {
+        n = (int)(pg / ((long)Ho * Wo));
+        int rem = (int)(pg - (long)n * Ho * Wo);
+        ho = rem / Wo;
+        wo = rem - ho * Wo;
+    }
+    // B-tile loader: 4 consecutive co of one k
+    const int bk = tid >> 4, bc = (tid & 15) * 4;
+
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    const int tap_lo = UPS ? blockIdx.z : 0;
+    const int tap_hi = UPS ? blockIdx.z + 1 : R * S;
+    for (int tap = tap_lo; tap < tap_hi; ++tap) {
+        int hi, wi;
+        if (UPS) { hi = ho; wi = wo; }
+        else {
+            int r = tap / S, s = tap - r * S;
+            hi = ho * stride - pad + r;
+            wi = wo * stride - pad + s;
+        }
+        const bool inb = pv && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        const TI* xp = x + ((long)((long)n * H + hi) * W + wi) * ldx;
+        for (int k0 = 0; k0 < Ci; k0 += GBK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int ci = k0 + lk + j;
+                float v = 0.f;
+                if (inb && ci < Ci) {
+                    v = (float)xp[ci];
+                    if (tx) v = umi_tx(v, tx[ci]);
+                }
+                As[lk + j][lp] = v;
+            }
+            {
+                int ci = k0 + bk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int co = c0 + bc + j;
+                    float v = 0.f;
+                    if (ci < Ci && co < Co) v = (float)wp[((long)tap * Ci + ci) * Co + co];
+                    Bs[bk][bc + j] = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < GBK; ++kk) {
+                float4 a = *(const float4*)&As[kk][tyi * 4];
+                float4 b = *(const float4*)&Bs[kk][txi * 4];
+                float av[4] = {a.x, a.y, a.z, a.w};
+                float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+            }
+            __syncthreads();
+        }
+    }
+
+    // epilogue: this thread owns pixels p0 + tyi*4 + i, channels c0 + txi*4 + j
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long pq = p0 + tyi * 4 + i;
+        if (pq >= P) continue;
+        int n2 = (int)(pq / ((long)Ho * Wo));
+        int rem = (int)(pq - (long)n2 * Ho * Wo);
+        int h2 = rem / Wo, w2 = rem - h2 * Wo;
+        if (UPS) {
+            h2 = 2 * h2 + (blockIdx.z >> 1) + off_h;
+            w2 = 2 * w2 + (blockIdx.z & 1) + off_w;
+            if (h2 < 0 || h2 >= out_H || w2 < 0 || w2 >= out_W) continue;
+        }
+        TO* yp = y + ((long)((long)n2 * out_H + h2) * out_W + w2) * ldy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int co = c0 + txi * 4 + j;
+            if (co < Co) {
+                float v = acc[i][j] + (bias ? bias[co] : 0.f);
+                TO o = (TO)v;
+                yp[co] = o;
+                float vr = (float)o;
+                ssum[j] += vr;
+                ssq[j] = fmaf(vr, vr, ssq[j]);
+            }
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[0][tyi][txi * 4 + j] = ssum[j];
+            red[1][tyi][txi * 4 + j] = ssq[j];
+        }
+        __syncthreads();
+        if (tid < 2 * GBC) {
+            int which = tid >> 6, c = tid & 63;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[which][r][c];
+            if (c0 + c < Co) part[((long)blockIdx.x * 2 + which) * Co + c0 + c] = s;
+        }
+    }
+}
+
+int umi_conv_fwd_generic(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy,
+                         float* stat_part, int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
+                         int Ho, int Wo, int off_h, int off_w, int out_H, int out_W, int in_dtype, int out_dtype,
+                         int flags, hipStream_t s) {
+    const bool ups = flags & UMI_CONV_UPSAMPLE2;
+    if (ups && (R != 2 || S != 2 || stat_part)) return UMI_ERR_BADARG;
+    long P = (long)N * Ho * Wo;
+    dim3 grid(umi_cdiv(P, GBP), umi_cdiv(Co, GBC), ups ? 4 : 1), block(256);
+#define LAUNCH(TI, TO, U)                                                                                        \
+    hipLaunchKernelGGL((conv_generic_kernel<TI, TO, U>), grid, block, 0, s, (const TI*)x, ldx, (const float4*)tx, \
+                       (const TI*)wp, bias, (TO*)y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,   \
+                       off_h, off_w, out_H, out_W)
+    if (in_dtype == UMI_F32 && out_dtype == UMI_F32) { if (ups) LAUNCH(float, float, true); else LAUNCH(float, float, false); }
+    else if (in_dtype == UMI_F16 && out_dtype == UMI_F16) { if (ups) LAUNCH(half_t, half_t, true); else LAUNCH(half_t, half_t, false); }
+    else if (in_dtype == UMI_F16 && out_dtype == UMI_F32) { if (ups) LAUNCH(half_t, float, true); else LAUNCH(half_t, float, false); }
+    else return UMI_ERR_UNSUPPORTED;
+#undef LAUNCH
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm statistics finalize: one block per channel, fixed-order double reduction.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float4* __restrict__ tx_out,
+                                                          float* __restrict__ rstd_out) {
+    __shared__ double sh[2][256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int r = tid; r < rows; r += 256) {
+        s += (double)part[((long)r * 2 + 0) * C + c];
+        q += (double)part[((long)r * 2 + 1) * C + c];
+    }
+    sh[0][tid] = s;
+    sh[1][tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double mean = sh[0][0] / count;
+        double var = sh[1][0] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double rstd = 1.0 / sqrt(var + (double)eps);
+        float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        tx_out[c] = make_float4((float)mean, (float)((double)g * rstd), b, 0.f);
+        if (rstd_out) rstd_out[c] = (float)rstd;
+        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        if (rvar) {
+            double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
+extern "C" int umi_bn_finalize(const float* stat_part, int rows, int C, double count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                               void* tx_out, float* rstd_out, umi_stream_t stream) {
+    if (!stat_part || !tx_out || rows <= 0 || C <= 0 || count <= 0) return UMI_ERR_BADARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, rows, C, count, gamma,
+                       beta, eps, momentum, running_mean, running_var, (float4*)tx_out, rstd_out);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool2d(2) forward / backward on the transformed tensor (thread = one output pixel x 4 channels)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pool2_fwd_kernel(const T* __restrict__ x, int ldx, const float4* __restrict__ tx, T* __restrict__ y,
+                                 int ldy, int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, C4 = (C + 3) / 4;
+    long total = (long)N * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cg = (int)(i % C4);
+        long p = i / C4;
+        int wo = (int)(p % Wo);
+        long r = p / Wo;
+        int ho = (int)(r % Ho);
+        int n = (int)(r / Ho);
+        for (int j = 0; j < 4; ++j) {
+            int c = cg * 4 + j;
+            if (c >= C) break;
+            float m = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int h = 2 * ho + (d >> 1), w = 2 * wo + (d & 1);
+                float v = (float)x[((long)((long)n * H + h) * W + w) * ldx + c];
+                if (tx) v = umi_tx(v, tx[c]);
+                m = (v > m) ? v : m;
+            }
+            y[((long)((long)n * Ho + ho) * Wo + wo) * ldy + c] = (T)m;
+        }
+    }
+}
+
+template <typename T>
+__global__ void pool2_bwd_kernel(const T* __restrict__ dp, int lddp, const T* __restrict__ x, int ldx,
+                                 const float4* __restrict__ tx, T* __restrict__ da, int ldda, int accumulate, int N,
+                                 int H, int W, int C) {
+    // one thread per (input pixel window, 4 channels): covers the full HxW input incl. odd tails
+    const int Hw = (H + 1) / 2, Ww = (W + 1) / 2, Ho = H / 2, Wo = W / 2, C4 = (C + 3) / 4;
+    long total = (long)N * Hw * Ww * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cg = (int)(i % C4);
+        long p = i / C4;
+        int wq = (int)(p % Ww);
+        long r = p / Ww;
+        int hq = (int)(r % Hw);
+        int n = (int)(r / Hw);
+        const bool win = hq < Ho && wq < Wo;
+        for (int j = 0; j < 4; ++j) {
+            int c = cg * 4 + j;
+            if (c >= C) break;
+            int best = -1;
+            float g = 0.f;
+            if (win) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    int h = 2 * hq + (d >> 1), w = 2 * wq + (d & 1);
+                    float v = (float)x[((long)((long)n * H + h) * W + w) * ldx + c];
+                    if (tx) v = umi_tx(v, tx[c]);
+                    if (v > m || best < 0) { m = v; best = d; }      // first max wins ties (PyTorch rule)
+                }
+                g = (float)dp[((long)((long)n * Ho + hq) * Wo + wq) * lddp + c];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int h = 2 * hq + (d >> 1), w = 2 * wq + (d & 1);
+                if (h >= H || w >= W) continue;
+                T* q = da + ((long)((long)n * H + h) * W + w) * ldda + c;
+                float v = (d == best) ? g : 0.f;
+                if (accumulate) v += (float)(*q);
+                *q = (T)v;
+            }
+        }
+    }
+}
+
+extern "C" int umi_pool2_fwd(const void* x, int ldx, const void* tx, void* y, int ldy, int N, int H, int W, int C,
+                             int dtype, umi_stream_t stream) {
+    if (N <= 0 || H < 2 || W < 2 || C <= 0) return UMI_ERR_BADARG;
+    long total = (long)N * (H / 2) * (W / 2) * ((C + 3) / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    if (dtype == UMI_F32) hipLaunchKernelGGL(pool2_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float4*)tx, (float*)y, ldy, N, H, W, C);
+    else if (dtype == UMI_F16) hipLaunchKernelGGL(pool2_fwd_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, (const float4*)tx, (half_t*)y, ldy, N, H, W, C);
+    else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_pool2_bwd(const void* dpool, int lddp, const void* x, int ldx, const void* tx, void* da, int ldda,
+                             int accumulate, int N, int H, int W, int C, int dtype, umi_stream_t stream) {
+    if (N <= 0 || H < 2 || W < 2 || C <= 0) return UMI_ERR_BADARG;
+    long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * ((C + 3) / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    if (dtype == UMI_F32) hipLaunchKernelGGL(pool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dpool, lddp, (const float*)x, ldx, (const float4*)tx, (float*)da, ldda, accumulate, N, H, W, C);
+    else if (dtype == UMI_F16) hipLaunchKernelGGL(pool2_bwd_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)dpool, lddp, (const half_t*)x, ldx, (const float4*)tx, (half_t*)da, ldda, accumulate, N, H, W, C);
+    else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm + ReLU backward: two-stage deterministic reduction, then elementwise apply.
+// Stage 1: block b reduces pixel rows [b*RPB, (b+1)*RPB) -> ws[b][2][C]; stage 2: one block / channel.
+// ------------------------------------------------------------------------------------------
+constexpr int BNB_RPB = 256;     // pixel rows per stage-1 block
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce1_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ y,
+                                                             int ldy, const float4* __restrict__ tx,
+                                                             const float* __restrict__ rstd, float* __restrict__ ws,
+                                                             long M, int C) {
+    // thread layout: 256 threads = (256/CT) pixel lanes x CT channel lanes, CT = min(C rounded up, 64)
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x;
+    const int CT = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
+    const int PL = 256 / CT;
+    const int cl = tid % CT, pl = tid / CT;
+    const long r0 = (long)blockIdx.x * BNB_RPB;
+    long r1 = r0 + BNB_RPB;
+    if (r1 > M) r1 = M;
+    for (int cb = 0; cb < C; cb += CT) {
+        int c = cb + cl;
+        float s = 0.f, q = 0.f;
+        if (c < C) {
+            const float4 t = tx[c];
+            const float rs = rstd[c];
+            for (long r = r0 + pl; r < r1; r += PL) {
+                float yv = (float)y[r * ldy + c];
+                float g = (float)da[r * ldda + c];
+                float z = umi_tx_pre(yv, t);
+                float dz = z > t.w ? g : 0.f;
+                s += dz;
+                q = fmaf(dz, (yv - t.x) * rs, q);
+            }
+        }
+        red[0][tid] = s;
+        red[1][tid] = q;
+        __syncthreads();
+        if (tid < CT) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < PL; ++k) { a += red[0][k * CT + tid]; b += red[1][k * CT + tid]; }
+            if (cb + tid < C) {
+                ws[((long)blockIdx.x * 2 + 0) * C + cb + tid] = a;
+                ws[((long)blockIdx.x * 2 + 1) * C + cb + tid] = b;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_rows2_kernel(const float* __restrict__ ws, int rows, int C,
+                                                           float* __restrict__ out0, float* __restrict__ out1,
+                                                           float scale) {
+    __shared__ double sh[2][256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int r = tid; r < rows; r += 256) {
+        s += (double)ws[((long)r * 2 + 0) * C + c];
+        if (out1) q += (double)ws[((long)r * 2 + 1) * C + c];
+    }
+    sh[0][tid] = s;
+    sh[1][tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out0[c] = (float)(sh[0][0] * (double)scale);
+        if (out1) out1[c] = (float)(sh[1][0] * (double)scale);
+    }
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(T* __restrict__ da, int ldda, const T* __restrict__ y, int ldy,
+                                    const float4* __restrict__ tx, const float* __restrict__ rstd,
+                                    const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx, long M, int C) {
+    const float invM = 1.f / (float)M;
+    long total = M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long r = i / C;
+        const float4 t = tx[c];
+        float yv = (float)y[r * ldy + c];
+        float g = (float)da[r * ldda + c];
+        float z = umi_tx_pre(yv, t);
+        float dz = z > t.w ? g : 0.f;
+        float xh = (yv - t.x) * rstd[c];
+        float dy = t.y * (dz - sum_dz[c] * invM - xh * sum_dzx[c] * invM);
+        da[r * ldda + c] = (T)dy;
+    }
+}
+
+extern "C" size_t umi_bn_bwd_ws_bytes(long M, int C) {
+    return (size_t)umi_cdiv(M, BNB_RPB) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int umi_bn_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd,
+                                 float* sum_dz, float* sum_dzx, long M, int C, int dtype, void* ws, size_t ws_bytes,
+                                 umi_stream_t stream) {
+    if (!da || !y || !tx || !rstd || M <= 0 || C <= 0) return UMI_ERR_BADARG;
+    if (ws_bytes < umi_bn_bwd_ws_bytes(M, C)) return UMI_ERR_WORKSPACE;
+    int rows = umi_cdiv(M, BNB_RPB);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F32) hipLaunchKernelGGL(bn_bwd_reduce1_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)da, ldda, (const float*)y, ldy, (const float4*)tx, rstd, (float*)ws, M, C);
+    else if (dtype == UMI_F16) hipLaunchKernelGGL(bn_bwd_reduce1_kernel<half_t>, dim3(rows), dim3(256), 0, s, (const half_t*)da, ldda, (const half_t*)y, ldy, (const float4*)tx, rstd, (float*)ws, M, C);
+    else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, rows, C, sum_dz, sum_dzx, 1.f);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_bn_bwd_apply(void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd,
+                                const float* sum_dz, const float* sum_dzx, long M, int C, int dtype,
+                                umi_stream_t stream) {
+    if (!da || !y || !tx || !rstd || M <= 0 || C <= 0) return UMI_ERR_BADARG;
+    long total = M * C;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)da, ldda, (const float*)y, ldy, (const float4*)tx, rstd, sum_dz, sum_dzx, M, C);
+    else if (dtype == UMI_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (half_t*)da, ldda, (const half_t*)y, ldy, (const float4*)tx, rstd, sum_dz, sum_dzx, M, C);
+    else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-channel column sum (bias gradients)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum1_kernel(const T* __restrict__ x, int ldx, float* __restrict__ ws, long M,
+                                                      int C) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int CT = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
+    const int PL = 256 / CT;
+    const int cl = tid % CT, pl = tid / CT;
+    const long r0 = (long)blockIdx.x * BNB_RPB;
+    long r1 = r0 + BNB_RPB;
+    if (r1 > M) r1 = M;
+    for (int cb = 0; cb < C; cb += CT) {
+        int c = cb + cl;
+        float s = 0.f;
+        if (c < C)
+            for (long r = r0 + pl; r < r1; r += PL) s += (float)x[r * ldx + c];
+        red[tid] = s;
+        __syncthreads();
+        if (tid < CT) {
+            float a = 0.f;
+            for (int k = 0; k < PL; ++k) a += red[k * CT + tid];
+            if (cb + tid < C) ws[((long)blockIdx.x * 2 + 0) * C + cb + tid] = a;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" size_t umi_colsum_ws_bytes(long M, int C) { return umi_bn_bwd_ws_bytes(M, C); }
+
+extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, long M, int C, int dtype, void* ws,
+                          size_t ws_bytes, umi_stream_t stream) {
+    if (!x || !out || M <= 0 || C <= 0) return UMI_ERR_BADARG;
+    if (ws_bytes < umi_colsum_ws_bytes(M, C)) return UMI_ERR_WORKSPACE;
+    int rows = umi_cdiv(M, BNB_RPB);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F32) hipLaunchKernelGGL(colsum1_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)ws, M, C);
+    else if (dtype == UMI_F16) hipLaunchKernelGGL(colsum1_kernel<half_t>, dim3(rows), dim3(256), 0, s, (const half_t*)x, ldx, (float*)ws, M, C);
+    else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, rows, C, out, (float*)nullptr, out_scale);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// generic weight gradient: per tap a [64 ci] x [64 co] tile, K = a chunk of output pixels
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_generic_kernel(
+    const T* __restrict__ x, int ldx, const float4* __restrict__ txa, const T* __restrict__ dy, int lddy,
+    const float4* __restrict__ txb, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int R, int S,
+    int stride, int pad, int Ho, int Wo, long chunk, int tiles_co) {
+    __shared__ __attribute__((aligned(16))) float As[GBK][64 + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK][64 + 4];
+    const int tid = threadIdx.x;
+    const int txi = tid & 15, tyi = tid >> 4;
+    const int tile_ci = blockIdx.x / tiles_co, tile_co = blockIdx.x % tiles_co;
+    const int ci0 = tile_ci * 64, co0 = tile_co * 64;
+    const int tap = blockIdx.y;
+    const int r = tap / S, s = tap - r * S;
+    const long P = (long)N * Ho * Wo;
+    const long k_begin = (long)blockIdx.z * chunk;
+    long k_end = k_begin + chunk;
+    if (k_end > P) k_end = P;
+
+    const int lk = tid >> 4;          // pixel within the K tile
+    const int lc = (tid & 15) * 4;    // 4 consecutive channels
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (long k0 = k_begin; k0 < k_end; k0 += GBK) {
+        long pg = k0 + lk;
+        bool pv = pg < k_end;
+        int n = 0, ho = 0, wo = 0;
+        if (pv) {
+            n = (int)(pg / ((long)Ho * Wo));
+            int rem = (int)(pg - (long)n * Ho * Wo);
+            ho = rem / Wo;
+            wo = rem - ho * Wo;
+        }
+        int hi = ho * stride - pad + r, wi = wo * stride - pad + s;
+        bool inb = pv && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        const T* xp = x + ((long)((long)n * H + hi) * W + wi) * ldx;
+        const T* dp = dy + pg * lddy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int ci = ci0 + lc + j;
+            float v = 0.f;
+            if (inb && ci < Ci) {
+                v = (float)xp[ci];
+                if (txa) v = umi_tx(v, txa[ci]);
+            }
+            As[lk][lc + j] = v;
+            int co = co0 + lc + j;
+            float g = 0.f;
+            if (pv && co < Co) {
+                g = (float)dp[co];
+                if (txb) g = umi_tx(g, txb[co]);
+            }
+            Bs[lk][lc + j] = g;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GBK; ++kk) {
+            float4 a = *(const float4*)&As[kk][tyi * 4];
+            float4 b = *(const float4*)&Bs[kk][txi * 4];
+            float av[4] = {a.x, a.y, a.z, a.w};
+            float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    // part[z][tap][ci][co]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ci = ci0 + tyi * 4 + i;
+        if (ci >= Ci) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int co = co0 + txi * 4 + j;
+            if (co < Co) part[(((long)blockIdx.z * R * S + tap) * Ci + ci) * Co + co] = acc[i][j];
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int RS, int Ci, int Co,
+                                    float* __restrict__ dW, long s_co, long s_ci, long s_t, float scale) {
+    long total = (long)RS * Ci * Co;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int co = (int)(i % Co);
+        long rr = i / Co;
+        int ci = (int)(rr % Ci);
+        int t = (int)(rr / Ci);
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += part[(long)z * total + i];
+        dW[co * s_co + ci * s_ci + t * s_t] = s * scale;
+    }
+}
+
+static void wgrad_generic_plan(long P, int Ci, int Co, int RS, int* splits, long* chunk) {
+    long tiles = (long)umi_cdiv(Ci, 64) * umi_cdiv(Co, 64) * RS;
+    long want = (2048 + tiles - 1) / tiles;          // aim for >= 2048 workgroups
+    long maxs = (P + 255) / 256;                     // at least 256 pixels per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    long ch = (P + want - 1) / want;
+    ch = (ch + GBK - 1) / GBK * GBK;
+    *chunk = ch;
+    *splits = (int)((P + ch - 1) / ch);
+}
+
+size_t umi_conv_wgrad_generic_ws_bytes(int N, int Ho, int Wo, int Ci, int Co, int R, int S) {
+    int splits; long chunk;
+    wgrad_generic_plan((long)N * Ho * Wo, Ci, Co, R * S, &splits, &chunk);
+    return (size_t)splits * R * S * Ci * Co * sizeof(float);
+}
+
+int umi_conv_wgrad_generic(const void* x, int ldx, const void* txa, const void* dy, int lddy, const void* txb, float* dW,
+                           long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, int R,
+                           int S, int stride, int pad, int Ho, int Wo, int dtype, void* ws, size_t ws_bytes,
+                           hipStream_t st) {
+    int splits; long chunk;
+    const long P = (long)N * Ho * Wo;
+    wgrad_generic_plan(P, Ci, Co, R * S, &splits, &chunk);
+    if (ws_bytes < (size_t)splits * R * S * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
+    const int tiles_co = umi_cdiv(Co, 64);
+    dim3 grid(umi_cdiv(Ci, 64) * tiles_co, R * S, splits), block(256);
+    if (dtype == UMI_F32) hipLaunchKernelGGL(wgrad_generic_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float4*)txa, (const float*)dy, lddy, (const float4*)txb, (float*)ws, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, chunk, tiles_co);
+    else if (dtype == UMI_F16) hipLaunchKernelGGL(wgrad_generic_kernel<half_t>, grid, block, 0, st, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (const float4*)txb, (float*)ws, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, chunk, tiles_co);
+    else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    long total = (long)R * S * Ci * Co;
+    int g = (int)((total + 255) / 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, (const float*)ws, splits, R * S, Ci, Co, dW, s_co, s_ci, s_t, out_scale);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// materialize an activation: NHWC storage + consumer transform -> NCHW fp32 (block outputs)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void materialize_nchw_kernel(const T* __restrict__ x, int ldx, const float4* __restrict__ tx,
+                                        float* __restrict__ y, int N, int H, int W, int C) {
+    long total = (long)N * C * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int w = (int)(i % W);
+        long r = i / W;
+        int h = (int)(r % H);
+        r /= H;
+        int c = (int)(r % C);
+        int n = (int)(r / C);
+        float v = (float)x[((long)((long)n * H + h) * W + w) * ldx + c];
+        if (tx) v = umi_tx(v, tx[c]);
+        y[i] = v;
+    }
+}
+
+extern "C" int umi_materialize_nchw(const void* x, int ldx, const void* tx, float* y, int N, int H, int W, int C,
+                                    int dtype, umi_stream_t stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return UMI_ERR_BADARG;
+    long total = (long)N * C * H * W;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F32) hipLaunchKernelGGL(materialize_nchw_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, (const float4*)tx, y, N, H, W, C);
+    else if (dtype == UMI_F16) hipLaunchKernelGGL(materialize_nchw_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)tx, y, N, H, W, C);
+    else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}

@@ -1,0 +1,292 @@
+"""Tape engine: forward/backward of conv-BN-ReLU encoder-decoder graphs on libunetmi kernels.
+
+Values are *lazily activated* NHWC tensors (`Act`): the stored tensor is the raw
+convolution output and `tx` ([C,4] = {mean, gamma*rstd, beta, clamp}) is the BatchNorm
++ReLU the consumer applies while loading it.  Concatenation is free: producers write
+into channel slices of one buffer and the concat `Act` just stacks the `tx` rows.
+
+The backward pass is hand-written (no torch autograd inside the graph): every op
+pushes a closure on the tape; `Tape.backward` replays them in reverse.  Gradients of
+activations are NHWC in the compute dtype and carry the static loss scale (fp16 mode);
+parameter gradients are produced in fp32, unscaled, in the parameter's own layout.
+
+Reference semantics implemented here: Model.py:7-26 (DoubleConv), :29-47 (Down),
+:50-83 (Up), :86-92 (OutConv); BatchNorm2d train/eval behaviour as torch.nn.
+"""
+import torch
+
+from . import lib as L
+from . import ops
+
+
+class Act:
+    """Lazily-activated NHWC tensor.  `raw` is an [N,H,W,C] view, `tx` the consumer transform
+    (None = consume as stored).  `grad` = d loss / d activated value (same layout/dtype)."""
+    __slots__ = ("raw", "tx", "grad", "parts", "needs_grad")
+
+    def __init__(self, raw, tx=None, parts=None, needs_grad=True):
+        self.raw, self.tx, self.grad, self.parts, self.needs_grad = raw, tx, None, parts, needs_grad
+
+    @property
+    def shape(self):
+        return tuple(self.raw.shape)
+
+    def full_tx(self):
+        return self.tx
+
+
+class Tape:
+    def __init__(self, dtype, training, record, loss_scale=1.0, grad_sink=None):
+        self.dtype = dtype
+        self.grad_sink = grad_sink        # umi.ddp.GradReducer (flat buckets + overlapped all-reduce) or None
+        self.training = training          # BatchNorm uses batch statistics
+        self.record = record              # keep closures for backward
+        self.loss_scale = float(loss_scale)
+        # parameter gradients leave the kernels multiplied by `inv`: undoes the loss scale and, under
+        # data parallelism, pre-divides by the world size so the all-reduce is a plain SUM
+        self.inv = (grad_sink.grad_scale if grad_sink is not None else 1.0) / self.loss_scale
+        self.steps = []
+        self.param_grads = {}             # id(param) -> (param, grad tensor)
+        self._inputs = []
+
+    # ---- helpers -----------------------------------------------------------------------
+    def alloc(self, N, H, W, C, dtype=None, zero=False, device=None):
+        f = torch.zeros if zero else torch.empty
+        return f((N, H, W, C), dtype=dtype or self.dtype, device=device)
+
+    def _new_pgrad(self, p):
+        """fp32 tensor the wgrad kernel writes into: a slot of the reducer's flat bucket when present."""
+        v = self.grad_sink.buffer_for(p) if self.grad_sink is not None else None
+        return v if v is not None else torch.empty_like(p, dtype=torch.float32)
+
+    def _set_pgrad(self, p, g):
+        key = id(p)
+        if key in self.param_grads:
+            self.param_grads[key][1].add_(g)
+            return
+        v = self.grad_sink.buffer_for(p) if self.grad_sink is not None else None
+        if v is not None:
+            if v.data_ptr() != g.data_ptr():
+                v.copy_(g)
+            g = v
+        self.param_grads[key] = (p, g)
+        if v is not None:
+            self.grad_sink.mark_ready(p)
+
+    def _give(self, act: Act, g):
+        """Route gradient `g` (NHWC view) to `act`; concat acts forward slices to their parts."""
+        if act.parts is not None:
+            for part, c0, c1 in act.parts:
+                self._give(part, g[..., c0:c1])
+            return
+        if not act.needs_grad:
+            return
+        if act.grad is None:
+            act.grad = g
+        else:
+            act.grad.add_(g)
+
+    # ---- graph inputs / outputs --------------------------------------------------------
+    def input_nchw(self, x: torch.Tensor, needs_grad=False):
+        if not x.is_cuda:
+            raise RuntimeError("unet-torch_amd: the HIP path needs the input on device 'cuda' (MI355X); "
+                               "no CPU fallback exists in the product path")
+        a = Act(x.permute(0, 2, 3, 1).contiguous().to(self.dtype), None, needs_grad=needs_grad)
+        self._inputs.append(a)
+        return a
+
+    def input_nhwc(self, raw, tx=None, needs_grad=False):
+        a = Act(raw, tx, needs_grad=needs_grad)
+        self._inputs.append(a)
+        return a
+
+    # ---- ops ---------------------------------------------------------------------------
+    def conv_bn(self, a: Act, weight, bn, out=None, stride=1, pad=1):
+        """Conv2d(bias=False) -> BatchNorm2d -> ReLU, the last two deferred to the consumer."""
+        Co, Ci, R, S = weight.shape
+        N, H, W, Ca = a.shape
+        assert Ca == Ci, f"conv expects {Ci} input channels, got {Ca}"
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        if out is None:
+            out = self.alloc(N, Ho, Wo, Co, device=a.raw.device)
+        wp = ops.pack_conv_fwd(weight.detach().float(), self.dtype)
+        part = ops.conv_fwd(a.raw, a.tx, wp, None, out, R, S, stride, pad, want_stats=self.training)
+        if self.training:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            tx, rstd = ops.bn_finalize(part, Co, N * Ho * Wo, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                                       bn.running_mean if bn.track_running_stats else None,
+                                       bn.running_var if bn.track_running_stats else None)
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        else:
+            tx, rstd = ops.eval_bn_tx(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        o = Act(out, tx)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                if not self.training:
+                    raise RuntimeError("backward through BatchNorm in eval mode is not supported by the HIP path")
+                inv = self.inv
+                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd)          # o.grad <- d(raw conv output)
+                self._set_pgrad(bn.weight, dgamma * inv)
+                self._set_pgrad(bn.bias, dbeta * inv)
+                gw = self._new_pgrad(weight)
+                ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad)
+                self._set_pgrad(weight, gw)
+                if _wants_grad(a):
+                    if stride != 1:
+                        raise NotImplementedError("dgrad for strided conv_bn")
+                    dx = self.alloc(N, H, W, Ci, device=out.device)
+                    wpd = ops.pack_conv_dgrad(weight.detach().float(), self.dtype)
+                    ops.conv_fwd(o.grad, None, wpd, None, dx, R, S, 1, R - 1 - pad)
+                    self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def conv_bias(self, a: Act, weight, bias, out_dtype=None, pad=0):
+        """Conv2d with bias, output consumed as stored (OutConv / segmentation head)."""
+        Co, Ci, R, S = weight.shape
+        N, H, W, Ca = a.shape
+        assert Ca == Ci
+        out = self.alloc(N, H + 2 * pad - R + 1, W + 2 * pad - S + 1, Co, dtype=out_dtype or self.dtype,
+                         device=a.raw.device)
+        wp = ops.pack_conv_fwd(weight.detach().float(), self.dtype)
+        ops.conv_fwd(a.raw, a.tx, wp, bias.detach().float() if bias is not None else None, out, R, S, 1, pad)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                inv = self.inv
+                g = o.grad
+                gw = self._new_pgrad(weight)
+                ops.conv_wgrad(a.raw, a.tx, g, None, gw, Ci * R * S, R * S, 1, inv, R, S, 1, pad)
+                self._set_pgrad(weight, gw)
+                if bias is not None:
+                    gb = self._new_pgrad(bias)
+                    ops.colsum(g, gb, inv)
+                    self._set_pgrad(bias, gb)
+                if _wants_grad(a):
+                    dx = self.alloc(N, H, W, Ci, device=out.device)
+                    wpd = ops.pack_conv_dgrad(weight.detach().float(), self.dtype)
+                    ops.conv_fwd(g, None, wpd, None, dx, R, S, 1, R - 1 - pad)
+                    self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def pool2(self, a: Act):
+        """MaxPool2d(2) of the activated tensor; result is stored activated."""
+        N, H, W, C = a.shape
+        out = self.alloc(N, H // 2, W // 2, C, device=a.raw.device)
+        ops.pool2_fwd(a.raw, a.tx, out)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None or not _wants_grad(a):
+                    return
+                if a.parts is not None:
+                    raise NotImplementedError("pool2 backward into a concat input")
+                if a.grad is None:
+                    a.grad = self.alloc(N, H, W, C, device=out.device)
+                    ops.pool2_bwd(o.grad, a.raw, a.tx, a.grad, False)
+                else:
+                    ops.pool2_bwd(o.grad, a.raw, a.tx, a.grad, True)
+            self.steps.append(bwd)
+        return o
+
+    def conv_transpose2x2(self, a: Act, weight, bias, dest, out_hw=None):
+        """ConvTranspose2d(k=2,s=2)+bias written into `dest` (a channel slice of a concat
+        buffer, spatial size = the skip's), centred like F.pad in reference Model.py:69-73."""
+        Cin, Cout = weight.shape[:2]
+        N, h, w, Ca = a.shape
+        assert Ca == Cin
+        _, Hd, Wd, Cd = dest.shape
+        assert Cd == Cout
+        dY, dX = Hd - 2 * h, Wd - 2 * w
+        if dY < 0 or dX < 0:
+            raise NotImplementedError("skip smaller than the upsampled map (negative F.pad) is not supported")
+        oy, ox = dY // 2, dX // 2
+        if dY or dX:
+            dest.zero_()
+        wp = ops.pack_convT_fwd(weight.detach().float(), self.dtype)
+        ops.conv_fwd(a.raw, a.tx, wp, bias.detach().float() if bias is not None else None, dest, 2, 2, 2, 0,
+                     flags=L.CONV_UPSAMPLE2, up_offset=(oy, ox))
+        o = Act(dest, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                inv = self.inv
+                g = o.grad
+                if dY or dX:
+                    g = g[:, oy:oy + 2 * h, ox:ox + 2 * w, :].contiguous()
+                if bias is not None:
+                    gb = self._new_pgrad(bias)
+                    ops.colsum(g, gb, inv)
+                    self._set_pgrad(bias, gb)
+                gw = self._new_pgrad(weight)
+                # dW[ci][co][t] = sum_p act(a)[p][ci] * g[2p+t][co]: a wgrad with the roles of x and dy swapped
+                ops.conv_wgrad(g, None, a.raw, a.tx, gw, Cout * 4, 4, 1, inv, 2, 2, 2, 0)
+                self._set_pgrad(weight, gw)
+                if _wants_grad(a):
+                    dx = self.alloc(N, h, w, Cin, device=dest.device)
+                    wpd = ops.pack_convT_dgrad(weight.detach().float(), self.dtype)
+                    ops.conv_fwd(g, None, wpd, None, dx, 2, 2, 2, 0)
+                    self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def concat(self, buf, acts):
+        """`acts` were produced into consecutive channel slices of `buf`."""
+        txs, parts, c0 = [], [], 0
+        for a in acts:
+            C = a.shape[3]
+            assert a.raw.data_ptr() == buf[..., c0:c0 + C].data_ptr(), "concat part is not a slice of the buffer"
+            txs.append(a.tx if a.tx is not None else ops.passthrough_tx(C, buf.device))
+            parts.append((a, c0, c0 + C))
+            c0 += C
+        assert c0 == buf.shape[3]
+        return Act(buf, torch.cat(txs, 0).contiguous(), parts=parts)
+
+    # ---- outputs -----------------------------------------------------------------------
+    def output_nchw_plain(self, a: Act):
+        """Plain (tx-free) fp32 NHWC act -> NCHW contiguous fp32 torch tensor."""
+        assert a.tx is None
+        return a.raw.permute(0, 3, 1, 2).contiguous().float()
+
+    def seed_grad_nchw(self, a: Act, g_nchw: torch.Tensor):
+        g = g_nchw.permute(0, 2, 3, 1)
+        if self.loss_scale != 1.0:
+            g = g * self.loss_scale
+        a.grad = g.to(self.dtype).contiguous()
+
+    def backward(self):
+        for step in reversed(self.steps):
+            step()
+        self.steps = []
+        if self.grad_sink is not None:
+            self.grad_sink.finish()
+
+    def input_grad_nchw(self, a: Act):
+        if a.grad is None:
+            return None
+        g = a.grad.permute(0, 3, 1, 2).float()
+        if self.loss_scale != 1.0:
+            g = g / self.loss_scale
+        return g.contiguous()
+
+
+def _wants_grad(a: Act):
+    if a.parts is not None:
+        return any(_wants_grad(p) for p, _, _ in a.parts)
+    return a.needs_grad
+
+
+def default_loss_scale(dtype, n_pixels):
+    """Static loss scale for fp16 gradients: activations' gradients are O(1/(N*H*W)), far below
+    fp16's normal range, so scale them to ~2^-4 (power of two: exact, undone in fp32)."""
+    if dtype != torch.float16:
+        return 1.0
+    import math
+    return float(2 ** max(0, int(math.floor(math.log2(max(n_pixels, 1)))) - 3))

@@ -1,0 +1,80 @@
+"""ctypes binding of libunetmi.so (declared in include/unetmi.h).
+
+The product path has NO CPU or eager-PyTorch fallback: if the shared library is
+missing and cannot be built, importing this module raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
+
+from . import build as _build
+
+UMI_F32, UMI_F16 = 0, 1
+CONV_UPSAMPLE2, CONV_FORCE_GENERIC = 1, 2
+
+_ERR = {-1: "UMI_ERR_BADARG", -2: "UMI_ERR_UNSUPPORTED", -3: "UMI_ERR_WORKSPACE"}
+
+
+def _load():
+    path = _build.LIB
+    if not os.path.exists(path) or (_build.stale() and os.path.exists(_build.HIPCC)):
+        if not os.path.exists(_build.HIPCC):
+            raise RuntimeError(
+                f"libunetmi.so not found at {path} and hipcc is unavailable: the HIP extension is "
+                "required, there is no CPU fallback (run `python __graft_entry__.py build`).")
+        _build.build_lib()
+    return ctypes.CDLL(path)
+
+
+_lib = _load()
+
+# name -> (restype, argtypes); mirrors include/unetmi.h one to one
+SIGNATURES = {
+    "umi_version": (c_int, []),
+    "umi_arch": (c_char_p, []),
+    "umi_pack_kn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_int, c_int,
+                            c_int, c_void_p]),
+    "umi_pack_kn8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_int, c_int,
+                             c_int, c_void_p]),
+    "umi_conv_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_conv_stat_rows": (c_int, [c_int] * 9),
+    "umi_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "umi_pool2_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_void_p]),
+    "umi_pool2_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                              c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_bn_bwd_ws_bytes": (c_size_t, [c_long, c_int]),
+    "umi_bn_bwd_reduce": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umi_bn_bwd_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_long, c_int, c_int, c_void_p]),
+    "umi_conv_wgrad_ws_bytes": (c_size_t, [c_int] * 9),
+    "umi_conv_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                               c_long, c_long, c_long, c_float,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umi_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
+    "umi_materialize_nchw": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_colsum": (c_int, [c_void_p, c_int, c_void_p, c_float, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_lib, _name)          # AttributeError here == header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"libunetmi: {what} failed with "
+                           f"{_ERR.get(status, 'hipError_t ' + str(status))}")
+
+
+def fn(name):
+    return getattr(_lib, name)
+
+
+lib = _lib

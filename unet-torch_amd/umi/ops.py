@@ -1,0 +1,212 @@
+"""Thin tensor-level wrappers over the libunetmi C ABI.
+
+PyTorch is used for device memory and streams only; every arithmetic op below is a
+HIP kernel in libunetmi.so.  Tensors are NHWC views `[N, H, W, C]` whose last dim is
+contiguous and whose pixel stride (`stride(2)`) may exceed C (channel slice of a
+concat buffer).
+"""
+import math
+
+import torch
+
+from . import lib as L
+
+NEG_INF = float("-inf")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.UMI_F32
+    if t.dtype == torch.float16:
+        return L.UMI_F16
+    raise TypeError(f"libunetmi supports float32/float16 storage, got {t.dtype}")
+
+
+def torch_dtype(code: int):
+    return torch.float32 if code == L.UMI_F32 else torch.float16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libunetmi ops need tensors on the MI355X (device 'cuda'); "
+                               "there is no CPU fallback in the product path")
+
+
+def _nhwc(t: torch.Tensor):
+    """Validate an NHWC view; returns (N, H, W, C, ld)."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError(f"expected NHWC view with contiguous channels, got {tuple(t.shape)} / {t.stride()}")
+    N, H, W, C = t.shape
+    ld = t.stride(2)
+    ok = ld >= C and (H == 1 or t.stride(1) == W * ld) and (N == 1 or t.stride(0) == H * W * ld)
+    if not ok:
+        raise ValueError(f"NHWC view must be dense in N,H,W with one pixel stride: {tuple(t.shape)} / {t.stride()}")
+    return N, H, W, C, ld
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def passthrough_tx(C, device):
+    """Transform rows for channels that are consumed as stored (no BN, no ReLU)."""
+    t = torch.zeros(C, 4, dtype=torch.float32, device=device)
+    t[:, 1] = 1.0
+    t[:, 3] = NEG_INF
+    return t
+
+
+def eval_bn_tx(weight, bias, running_mean, running_var, eps):
+    """Consumer transform for BatchNorm in eval mode (running statistics) + ReLU."""
+    rstd = torch.rsqrt(running_var.float() + eps)
+    return torch.stack([running_mean.float(), weight.float() * rstd, bias.float(),
+                        torch.zeros_like(rstd)], dim=1).contiguous(), rstd
+
+
+# ------------------------------------------------------------------------------------------
+def pack_kn(src: torch.Tensor, T, K, N, st, sk, sn, flip_t, dtype, Kpad=None, Npad=None, k8=False):
+    _need_cuda(src)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    Kpad, Npad = Kpad or K, Npad or N
+    out = torch.empty(T * Kpad * Npad, dtype=dtype, device=src.device)
+    f = L.fn("umi_pack_kn8" if k8 else "umi_pack_kn")
+    L.check(f(src.data_ptr(), out.data_ptr(), T, K, N, st, sk, sn, int(flip_t), Kpad, Npad, _dt(out), _stream()),
+            "umi_pack_kn")
+    return out
+
+
+def pack_conv_fwd(w: torch.Tensor, dtype, Kpad=None):
+    """OIHW -> [R*S][Ci][Co]."""
+    Co, Ci, R, S = w.shape
+    return pack_kn(w, R * S, Ci, Co, 1, R * S, Ci * R * S, False, dtype, Kpad=Kpad)
+
+
+def pack_conv_dgrad(w: torch.Tensor, dtype):
+    """OIHW -> rotated/transposed [R*S][Co][Ci] so dgrad is a plain forward conv (stride 1)."""
+    Co, Ci, R, S = w.shape
+    return pack_kn(w, R * S, Co, Ci, 1, Ci * R * S, R * S, True, dtype)
+
+
+def pack_convT_fwd(w: torch.Tensor, dtype):
+    """ConvTranspose2d [Cin][Cout][2][2] -> [4][Cin][Cout]."""
+    Cin, Cout = w.shape[:2]
+    return pack_kn(w, 4, Cin, Cout, 1, Cout * 4, 4, False, dtype)
+
+
+def pack_convT_dgrad(w: torch.Tensor, dtype):
+    """ConvTranspose2d [Cin][Cout][2][2] -> [4][Cout][Cin] (stride-2 2x2 conv over d(up))."""
+    Cin, Cout = w.shape[:2]
+    return pack_kn(w, 4, Cout, Cin, 1, 4, Cout * 4, False, dtype)
+
+
+# ------------------------------------------------------------------------------------------
+def conv_fwd(x, tx, wp, bias, y, R, S, stride, pad, want_stats=False, flags=0, up_offset=(0, 0)):
+    """y <- conv(tx(x), wp) [+ bias]; returns the stats-partials tensor when want_stats."""
+    _need_cuda(x, wp, y)
+    N, H, W, Ci, ldx = _nhwc(x)
+    N2, oH, oW, Co, ldy = _nhwc(y)
+    assert N2 == N
+    if flags & L.CONV_UPSAMPLE2:
+        Ho, Wo = H, W
+    else:
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        assert (oH, oW) == (Ho, Wo), f"output view {oH}x{oW} != conv output {Ho}x{Wo}"
+    part = None
+    if want_stats:
+        rows = L.fn("umi_conv_stat_rows")(N, Ho, Wo, Ci, Co, R, S, _dt(x), flags)
+        part = torch.empty(rows * 2 * Co, dtype=torch.float32, device=x.device)
+    if tx is not None:
+        assert tx.shape == (Ci, 4) and tx.dtype == torch.float32 and tx.is_contiguous()
+    L.check(L.fn("umi_conv_fwd")(x.data_ptr(), ldx, _ptr(tx), wp.data_ptr(), _ptr(bias), y.data_ptr(), ldy,
+                                 _ptr(part), N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
+                                 up_offset[0], up_offset[1], oH, oW, _dt(x), _dt(y), flags, _stream()),
+            "umi_conv_fwd")
+    return part
+
+
+def bn_finalize(part, C, count, gamma, beta, eps, momentum, running_mean, running_var):
+    rows = part.numel() // (2 * C)
+    tx = torch.empty(C, 4, dtype=torch.float32, device=part.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=part.device)
+    L.check(L.fn("umi_bn_finalize")(part.data_ptr(), rows, C, float(count), _ptr(gamma), _ptr(beta), eps, momentum,
+                                    _ptr(running_mean), _ptr(running_var), tx.data_ptr(), rstd.data_ptr(),
+                                    _stream()), "umi_bn_finalize")
+    return tx, rstd
+
+
+def pool2_fwd(x, tx, y):
+    N, H, W, C, ldx = _nhwc(x)
+    _, Ho, Wo, _, ldy = _nhwc(y)
+    assert (Ho, Wo) == (H // 2, W // 2)
+    L.check(L.fn("umi_pool2_fwd")(x.data_ptr(), ldx, _ptr(tx), y.data_ptr(), ldy, N, H, W, C, _dt(x), _stream()),
+            "umi_pool2_fwd")
+
+
+def pool2_bwd(dpool, x, tx, da, accumulate):
+    N, H, W, C, ldx = _nhwc(x)
+    _, _, _, _, lddp = _nhwc(dpool)
+    _, _, _, _, ldda = _nhwc(da)
+    L.check(L.fn("umi_pool2_bwd")(dpool.data_ptr(), lddp, x.data_ptr(), ldx, _ptr(tx), da.data_ptr(), ldda,
+                                  int(accumulate), N, H, W, C, _dt(x), _stream()), "umi_pool2_bwd")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device+stream (split-K slabs, reduction partials)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def bn_bwd(da, y, tx, rstd):
+    """In place: da <- dy.  Returns (sum_dz, sum_dzx) = (d beta, d gamma) (still loss-scaled)."""
+    N, H, W, C, ldy = _nhwc(y)
+    _, _, _, _, ldda = _nhwc(da)
+    M = N * H * W
+    nb = L.fn("umi_bn_bwd_ws_bytes")(M, C)
+    ws = workspace(nb, y.device)
+    sums = torch.empty(2, C, dtype=torch.float32, device=y.device)
+    L.check(L.fn("umi_bn_bwd_reduce")(da.data_ptr(), ldda, y.data_ptr(), ldy, tx.data_ptr(), rstd.data_ptr(),
+                                      sums[0].data_ptr(), sums[1].data_ptr(), M, C, _dt(y), ws.data_ptr(),
+                                      ws.numel(), _stream()), "umi_bn_bwd_reduce")
+    L.check(L.fn("umi_bn_bwd_apply")(da.data_ptr(), ldda, y.data_ptr(), ldy, tx.data_ptr(), rstd.data_ptr(),
+                                     sums[0].data_ptr(), sums[1].data_ptr(), M, C, _dt(y), _stream()),
+            "umi_bn_bwd_apply")
+    return sums[0], sums[1]
+
+
+def conv_wgrad(x, txa, dy, txb, dW, s_co, s_ci, s_t, out_scale, R, S, stride, pad, flags=0):
+    N, H, W, Ci, ldx = _nhwc(x)
+    _, Ho, Wo, Co, lddy = _nhwc(dy)
+    assert dW.dtype == torch.float32 and dW.is_contiguous()
+    nb = L.fn("umi_conv_wgrad_ws_bytes")(N, Ho, Wo, Ci, Co, R, S, _dt(x), flags)
+    ws = workspace(nb, x.device)
+    L.check(L.fn("umi_conv_wgrad")(x.data_ptr(), ldx, _ptr(txa), dy.data_ptr(), lddy, _ptr(txb), dW.data_ptr(),
+                                   s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
+                                   _dt(x), flags, ws.data_ptr(), ws.numel(), _stream()), "umi_conv_wgrad")
+
+
+def colsum(x, out, out_scale):
+    N, H, W, C, ldx = _nhwc(x)
+    M = N * H * W
+    ws = workspace(L.fn("umi_colsum_ws_bytes")(M, C), x.device)
+    L.check(L.fn("umi_colsum")(x.data_ptr(), ldx, out.data_ptr(), out_scale, M, C, _dt(x), ws.data_ptr(),
+                               ws.numel(), _stream()), "umi_colsum")
+
+
+def materialize_nchw(x, tx):
+    N, H, W, C, ldx = _nhwc(x)
+    y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    L.check(L.fn("umi_materialize_nchw")(x.data_ptr(), ldx, _ptr(tx), y.data_ptr(), N, H, W, C, _dt(x), _stream()),
+            "umi_materialize_nchw")
+    return y
