@@ -105,6 +105,13 @@ def cpu_baseline(cin, ncls, f, H, W, budget_s=25.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    try:                                   # container CPU quota (cgroup v2): "<quota> <period>" or "max <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, int(os.environ.get("UMI_CPU_BASELINE_THREADS", "16")))   # a one-GPU box's CPU share
     torch.set_num_threads(cores)
     m = ref_unet.RefUNet(cin, ncls, f, False).train()
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
@@ -199,7 +206,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms = dt / a.steps * 1e3

@@ -38,9 +38,8 @@ class _TapeFunction(torch.autograd.Function):
     """Bridges a libunetmi tape into torch.autograd: one node for the whole block/network."""
 
     @staticmethod
-    def forward(ctx, run, n_inputs, *tensors):
+    def forward(ctx, run, record, n_inputs, *tensors):
         inputs, params = tensors[:n_inputs], tensors[n_inputs:]
-        record = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
         tape, in_acts, out_act, out = run(record, [bool(t.requires_grad) for t in inputs])
         ctx.tape, ctx.in_acts, ctx.out_act, ctx.params, ctx.n_inputs = tape, in_acts, out_act, params, n_inputs
         return out
@@ -54,13 +53,13 @@ class _TapeFunction(torch.autograd.Function):
         tape.seed_grad_nchw(ctx.out_act, gout)
         tape.backward()
         gin = [tape.input_grad_nchw(a) if need else None
-               for a, need in zip(ctx.in_acts, ctx.needs_input_grad[2:2 + ctx.n_inputs])]
+               for a, need in zip(ctx.in_acts, ctx.needs_input_grad[3:3 + ctx.n_inputs])]
         gpar = []
-        for p, need in zip(ctx.params, ctx.needs_input_grad[2 + ctx.n_inputs:]):
+        for p, need in zip(ctx.params, ctx.needs_input_grad[3 + ctx.n_inputs:]):
             g = tape.param_grads.get(id(p))
             gpar.append(g[1].to(p.dtype) if (g is not None and need) else None)
         ctx.tape = None
-        return (None, None, *gin, *gpar)
+        return (None, None, None, *gin, *gpar)
 
 
 def _run_tape(module, inputs, build):
@@ -82,7 +81,9 @@ def _run_tape(module, inputs, build):
             out = ops.materialize_nchw(out_act.raw, out_act.tx)
         return tape, acts, out_act, out
 
-    return _TapeFunction.apply(run, len(inputs), *inputs, *params)
+    # grad mode is off inside Function.forward, so decide here whether to record the tape
+    record = torch.is_grad_enabled() and any(t.requires_grad for t in (*inputs, *params))
+    return _TapeFunction.apply(run, record, len(inputs), *inputs, *params)
 
 
 class _UmiModule(nn.Module):

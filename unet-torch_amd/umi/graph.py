@@ -91,7 +91,10 @@ class Tape:
         if not x.is_cuda:
             raise RuntimeError("unet-torch_amd: the HIP path needs the input on device 'cuda' (MI355X); "
                                "no CPU fallback exists in the product path")
-        a = Act(x.permute(0, 2, 3, 1).contiguous().to(self.dtype), None, needs_grad=needs_grad)
+        N, C, H, W = x.shape
+        raw = torch.empty((N, H, W, C), dtype=self.dtype, device=x.device)
+        raw.copy_(x.permute(0, 2, 3, 1))               # NCHW -> NHWC + dtype cast in one pass
+        a = Act(raw, None, needs_grad=needs_grad)
         self._inputs.append(a)
         return a
 
@@ -256,10 +259,12 @@ class Tape:
         return a.raw.permute(0, 3, 1, 2).contiguous().float()
 
     def seed_grad_nchw(self, a: Act, g_nchw: torch.Tensor):
+        N, C, H, W = g_nchw.shape
         g = g_nchw.permute(0, 2, 3, 1)
         if self.loss_scale != 1.0:
             g = g * self.loss_scale
-        a.grad = g.to(self.dtype).contiguous()
+        a.grad = torch.empty((N, H, W, C), dtype=self.dtype, device=g_nchw.device)
+        a.grad.copy_(g)
 
     def backward(self):
         for step in reversed(self.steps):

@@ -39,10 +39,10 @@ def _need_cuda(*ts):
 
 def _nhwc(t: torch.Tensor):
     """Validate an NHWC view; returns (N, H, W, C, ld)."""
-    if t.dim() != 4 or t.stride(3) != 1:
+    if t.dim() != 4 or (t.stride(3) != 1 and t.shape[3] != 1):
         raise ValueError(f"expected NHWC view with contiguous channels, got {tuple(t.shape)} / {t.stride()}")
     N, H, W, C = t.shape
-    ld = t.stride(2)
+    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else (t.stride(0) // max(H * W, 1) if N > 1 else C))
     ok = ld >= C and (H == 1 or t.stride(1) == W * ld) and (N == 1 or t.stride(0) == H * W * ld)
     if not ok:
         raise ValueError(f"NHWC view must be dense in N,H,W with one pixel stride: {tuple(t.shape)} / {t.stride()}")
