@@ -75,13 +75,15 @@ def measure_conv_roofline(device, dtype, cin, f, H, W, B, reps=5):
         tx = ops.passthrough_tx(ci, device)
         tx[:, 3] = 0.0                                           # BN-apply + ReLU on load, like the real step
         y = torch.empty(n, h, w, co, device=device, dtype=dtype)
-        wp = ops.pack_conv_fwd(wgt, dtype)
-        ops.conv_fwd(x, tx, wp, None, y, 3, 3, 1, 1, want_stats=True)
+        lay, _ = ops.conv_plan(x, y, 3, 3, 1, 1)
+        wp = ops.pack_conv_fwd(wgt, dtype, k8=bool(lay))
+        wpf = lambda _lay, wp=wp: wp
+        ops.conv_fwd(x, tx, wpf, None, y, 3, 3, 1, 1, want_stats=True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.conv_fwd(x, tx, wp, None, y, 3, 3, 1, 1, want_stats=True)
+            ops.conv_fwd(x, tx, wpf, None, y, 3, 3, 1, 1, want_stats=True)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps

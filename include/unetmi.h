@@ -67,7 +67,12 @@ int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* wp, const f
                  int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
                  int Ho, int Wo, int off_h, int off_w, int out_H, int out_W,
                  int in_dtype, int out_dtype, int flags, umi_stream_t stream);
-int umi_conv_stat_rows(int N, int Ho, int Wo, int Ci, int Co, int R, int S, int in_dtype, int flags);
+/* Which kernel umi_conv_fwd will take for this problem: *layout = 0 -> weights packed with umi_pack_kn,
+ * 1 -> umi_pack_kn8 (MFMA path: fp16, 3x3, stride 1, pad 1, Ci%16==0, Co%64==0, no bias, 16-B aligned
+ * rows); *stat_rows = rows of `stat_part` the call will write. */
+int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
+                      int ldx, int ldy, int in_dtype, int out_dtype, int flags, int has_bias,
+                      int* layout, int* stat_rows);
 
 /* BatchNorm2d training statistics -> consumer transform (reference Model.py:17,21 =
  * nn.BatchNorm2d: biased batch variance for normalisation, unbiased into running_var,

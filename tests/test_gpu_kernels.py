@@ -1,0 +1,121 @@
+"""Kernel-level GPU parity: every libunetmi op against plain PyTorch fp32 (CPU) on odd shapes, and the
+MFMA fast paths against the generic kernels (UMI_CONV_FORCE_GENERIC) on the same inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    from umi import lib, ops
+    return lib, ops
+
+
+def _tx(C, gen, relu=True):
+    t = torch.empty(C, 4)
+    t[:, 0] = 0.3 * torch.randn(C, generator=gen)
+    t[:, 1] = (0.5 + torch.rand(C, generator=gen)) * torch.where(torch.rand(C, generator=gen) < 0.15, -1.0, 1.0)
+    t[:, 2] = 0.2 * torch.randn(C, generator=gen)
+    t[:, 3] = 0.0 if relu else float("-inf")
+    return t
+
+
+def _apply_tx(x_nhwc, t):
+    return torch.maximum((x_nhwc - t[:, 0]) * t[:, 1] + t[:, 2], t[:, 3])
+
+
+def _ref_conv(x_nhwc, t, w, stride=1, pad=1):
+    a = _apply_tx(x_nhwc.float(), t) if t is not None else x_nhwc.float()
+    return F.conv2d(a.permute(0, 3, 1, 2), w, None, stride, pad).permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [  # N, H, W, Ci, Co, ldx_extra, ldy_extra, use_tx
+    (2, 20, 45, 32, 64, 0, 0, True),       # odd spatial size, BN=64 tile config
+    (1, 16, 64, 64, 128, 0, 0, True),      # BN=128 tile config
+    (2, 9, 33, 16, 192, 16, 64, True),     # channel-slice views (ld > C), 3 co-blocks of 64
+    (1, 40, 32, 128, 256, 0, 128, False),  # no transform (dgrad-style), output into a concat half
+    (3, 7, 5, 48, 64, 16, 0, True),        # image smaller than one tile
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3x3_mfma_vs_reference_and_generic(case):
+    lib, ops = _gpu()
+    N, H, W, Ci, Co, ex, ey, use_tx = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    xb = torch.randn(N, H, W, Ci + ex, generator=g).half()
+    x = xb[..., ex // 2: ex // 2 + Ci] if ex else xb
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5
+    t = _tx(Ci, g) if use_tx else None
+    ref = _ref_conv(x, t, w.half().float())
+    xd_b = xb.to(DEV)
+    xd = xd_b[..., ex // 2: ex // 2 + Ci] if ex else xd_b
+    td = t.to(DEV).contiguous() if use_tx else None
+    wd = w.to(DEV)
+    outs = {}
+    for name, flags in (("mfma", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        yb = torch.full((N, H, W, Co + ey), 7.0, device=DEV, dtype=torch.float16)
+        y = yb[..., ey // 2: ey // 2 + Co] if ey else yb
+        lay, rows = ops.conv_plan(xd, y, 3, 3, 1, 1, flags)
+        assert lay == (1 if name == "mfma" else 0)
+        part = ops.conv_fwd(xd, td, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), None, y, 3, 3, 1, 1,
+                            want_stats=True, flags=flags)
+        torch.cuda.synchronize()
+        if ey:      # bytes outside the channel slice are untouched
+            assert (yb[..., : ey // 2] == 7.0).all() and (yb[..., ey // 2 + Co:] == 7.0).all()
+        outs[name] = (y.float().cpu(), part.view(-1, 2, Co).sum(0).cpu())
+        assert part.numel() == rows * 2 * Co
+    ym, sm = outs["mfma"]
+    yg, sg = outs["generic"]
+    scale = ref.abs().max().item()
+    # the MFMA path rounds the activated input to fp16 before the matrix core; the generic one keeps fp32
+    assert (ym - ref).abs().max().item() < 4e-3 * scale
+    assert (yg - ref).abs().max().item() < 2e-3 * scale
+    assert (ym - yg).abs().max().item() < 4e-3 * scale
+    # BatchNorm partial sums are taken over the stored (rounded) outputs
+    for (y_, s_) in ((ym, sm), (yg, sg)):
+        torch.testing.assert_close(s_[0], y_.sum((0, 1, 2)), rtol=1e-3, atol=1e-2 * scale)
+        torch.testing.assert_close(s_[1], (y_ * y_).sum((0, 1, 2)), rtol=1e-3, atol=1e-2 * scale * scale)
+
+
+def test_conv3x3_mfma_dgrad_matches_autograd():
+    """dgrad = the same kernel on rotated/transposed weights: compare with torch autograd of conv2d."""
+    lib, ops = _gpu()
+    N, H, W, Ci, Co = 2, 24, 40, 64, 128
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).half().float()
+    dy = torch.randn(N, H, W, Co, generator=g).half()
+    xr = torch.zeros(N, Ci, H, W, requires_grad=True)
+    F.conv2d(xr, w, None, 1, 1).backward(dy.float().permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1)
+    dx = torch.empty(N, H, W, Ci, device=DEV, dtype=torch.float16)
+    wd = w.to(DEV)
+    ops.conv_fwd(dy.to(DEV), None, lambda l: ops.pack_conv_dgrad(wd, torch.float16, k8=bool(l)), None, dx, 3, 3, 1, 1)
+    assert ops.conv_plan(dy.to(DEV), dx, 3, 3, 1, 1)[0] == 1
+    assert (dx.float().cpu() - ref).abs().max().item() < 3e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 45, 32, 64), (1, 16, 64, 64, 128), (2, 9, 33, 16, 192), (1, 12, 12, 128, 64)])
+def test_wgrad_fast_path_vs_reference_and_generic(shape):
+    lib, ops = _gpu()
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, H, W, Ci, generator=g).half()
+    dy = (torch.randn(N, H, W, Co, generator=g) * 0.1).half()
+    t = _tx(Ci, g)
+    a = _apply_tx(x.float(), t).permute(0, 3, 1, 2).requires_grad_(False)
+    wr = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(a, wr, None, 1, 1).backward(dy.float().permute(0, 3, 1, 2))
+    ref = wr.grad * 0.5
+    res = {}
+    for name, flags in (("fast", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        gw = torch.empty(Co, Ci, 3, 3, device=DEV)
+        ops.conv_wgrad(x.to(DEV), t.to(DEV), dy.to(DEV), None, gw, Ci * 9, 9, 1, 0.5, 3, 3, 1, 1, flags=flags)
+        res[name] = gw.cpu()
+    scale = ref.abs().max().item()
+    assert (res["generic"] - ref).abs().max().item() < 2e-3 * scale
+    assert (res["fast"] - ref).abs().max().item() < 6e-3 * scale

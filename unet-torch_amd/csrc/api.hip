@@ -28,10 +28,18 @@ int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, i
 extern "C" int umi_version(void) { return 1; }
 extern "C" const char* umi_arch(void) { return "gfx950"; }
 
-extern "C" int umi_conv_stat_rows(int N, int Ho, int Wo, int Ci, int Co, int R, int S, int in_dtype, int flags) {
-    // The MFMA path (when taken) never needs more rows than the generic one.
-    (void)Ci; (void)Co; (void)R; (void)S; (void)in_dtype; (void)flags;
-    return umi_cdiv((long)N * Ho * Wo, 64);
+extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int ldx,
+                                 int ldy, int in_dtype, int out_dtype, int flags, int has_bias, int* layout,
+                                 int* stat_rows) {
+    if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || R <= 0 || S <= 0 || stride <= 0) return UMI_ERR_BADARG;
+    const bool ups = flags & UMI_CONV_UPSAMPLE2;
+    const int Ho = ups ? H : (H + 2 * pad - R) / stride + 1, Wo = ups ? W : (W + 2 * pad - S) / stride + 1;
+    static const float one = 1.f;
+    const bool mfma = umi_conv3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, in_dtype, out_dtype,
+                                          flags, has_bias ? &one : nullptr);
+    if (layout) *layout = mfma ? 1 : 0;
+    if (stat_rows) *stat_rows = mfma ? umi_conv3x3_mfma_stat_rows(N, H, W, Co) : umi_cdiv((long)N * Ho * Wo, 64);
+    return UMI_OK;
 }
 
 extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy,
@@ -46,6 +54,12 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
         if (out_H != Ho || out_W != Wo || off_h || off_w) return UMI_ERR_BADARG;
     } else {
         if (Ho != H || Wo != W) return UMI_ERR_BADARG;
+    }
+    if (umi_conv3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, in_dtype, out_dtype, flags, bias)) {
+        // the caller packed the weights for this path (umi_conv_fwd_plan said layout 1): misalignment is an error,
+        // not a reason to silently reinterpret them
+        if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wp) & 15) return UMI_ERR_BADARG;
+        return umi_conv3x3_mfma(x, ldx, tx, wp, y, ldy, stat_part, N, H, W, Ci, Co, (hipStream_t)stream);
     }
     return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
                                 off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);

@@ -1,0 +1,267 @@
+// conv3x3 (stride 1, pad 1) forward / dgrad on the gfx950 matrix cores, fp16 storage, fp32 accumulate.
+//
+// Implicit GEMM, D[co][pixel] += W[co][k] * X[k][pixel] with v_mfma_f32_32x32x16_f16:
+//   * A operand = weights  (M = 32 output channels, K = 16 input channels of one tap)
+//   * B operand = pixels   (N = 32 consecutive pixels of one image row, same K)
+// so the im2col shift of a tap is just an LDS address offset ("im2col in register").
+//
+// Workgroup = 256 threads = 4 waves, 2 workgroups per CU.  Tile = TH x 32 output pixels x BN channels:
+//   BN = 128: TH = 8  (waves 2 x 2)      BN = 64: TH = 16 (waves 4 x 1)
+// every wave owns 4 image rows x 64 channels = acc[2][4] 32x32 tiles (128 accumulator registers).
+//
+// Per 16-input-channel chunk the workgroup stages, through registers,
+//   * the (TH+2) x 34 halo tile of the input with the producer's BatchNorm+ReLU applied on the fly
+//     (consumer-side transform, zero padding applied AFTER it) and
+//   * the chunk's 9 taps x BN x 16 weights
+// into LDS with 48-byte rows (32 B data + 16 B pad: an odd number of 16-B slots, so the 16-lane
+// groups of ds_read_b128 fall on distinct slots -> conflict free for both operands).
+// Global loads of chunk c+1 are issued before the MFMA phase of chunk c and land in registers while it
+// runs (issue-early / write-late staging); the second resident workgroup covers what is left.
+// Each tap column dx reuses 6 pixel-row fragments for its 3 taps x 4 rows.
+//
+// Epilogue: accumulators -> fp16 -> LDS tile [pixel][BN] -> coalesced 16-B global stores, and the
+// per-channel sum / sum-of-squares of the *stored* values (BatchNorm statistics) are taken column-wise
+// from that LDS tile and written as one deterministic partial row per pixel tile.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int HALO_W = 34;      // 32 + 2
+constexpr int ROWB = 48;        // LDS bytes per pixel / weight row (16 halfs + 16 B pad)
+
+template <int TH, int BN>
+struct Cfg {
+    static constexpr int WN = BN / 64;
+    static constexpr int WM = 4 / WN;
+    static_assert(TH / WM == 4, "every wave owns 4 image rows");
+    static constexpr int HALO_PIX = (TH + 2) * HALO_W;
+    static constexpr int HB = HALO_PIX * ROWB;
+    static constexpr int WB = 9 * BN * ROWB;
+    static constexpr int P = TH * 32;
+    static constexpr int ERS = BN * 2 + 16;          // epilogue LDS row stride (bytes)
+    static constexpr int EB = P * ERS;
+    static constexpr int SMEM = (HB + WB) > EB ? (HB + WB) : EB;
+    static constexpr int NPH = 2 * HALO_PIX;         // 16-B pieces of the halo tile per chunk
+    static constexpr int KPH = (NPH + 255) / 256;
+    static constexpr int NPW = 9 * BN * 2;           // 16-B pieces of the weights per chunk
+    static constexpr int KPW = (NPW + 255) / 256;
+};
+
+template <int TH, int BN, bool HAS_TX, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
+    const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
+    half_t* __restrict__ y, int ldy, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x,
+    int tiles_y, int n_co) {
+    using C = Cfg<TH, BN>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];
+    __shared__ float red[2][4][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave % C::WN, wm = wave / C::WN;
+
+    const int cb = blockIdx.x % n_co;
+    const int pt = blockIdx.x / n_co;
+    const int n = pt / (tiles_x * tiles_y);
+    const int rem = pt - n * tiles_x * tiles_y;
+    const int ty0 = (rem / tiles_x) * TH, tx0 = (rem % tiles_x) * 32;
+    const int c0 = cb * BN;
+    const int q = tid & 1;                         // which 8-channel half of the 16-channel chunk this thread stages
+
+    // ---- per-thread staging plan (fixed across chunks) ------------------------------------------
+    // halo piece k of this thread: index i = tid + 256k -> halo pixel hp = (tid>>1) + 128k, channel half q
+    int pix[C::KPH];                               // linear pixel index inside image n, or -1 (zero padding / no piece)
+#pragma unroll
+    for (int k = 0; k < C::KPH; ++k) {
+        int hp = (tid >> 1) + 128 * k;
+        int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        bool inimg = (hp < C::HALO_PIX) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        pix[k] = inimg ? gy * W + gx : -1;
+    }
+    const half_t* xin = x + (long)n * H * W * ldx + q * 8;
+    const int hl_base = (tid >> 1) * ROWB + q * 16;           // + k * 128 * ROWB
+    // weight piece k: row rc = (tid>>1) + 128k of the [9*BN] rows -> tap = k*(128/BN) + (tid>>1)/BN
+    constexpr int TSTEP = 128 / BN;
+    const int tap0 = (tid >> 1) / BN, wcol = (tid >> 1) % BN;
+    const int Ci8 = Ci >> 3;
+    const half_t* win = wp8 + ((long)((long)tap0 * Ci8 + q) * Co + c0 + wcol) * 8;
+    const long wstep = (long)TSTEP * Ci8 * Co * 8;              // elements per k step
+    const int wl_base = C::HB + (tid >> 1) * ROWB + q * 16;    // + k * 128 * ROWB
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    half8 hraw[C::KPH], wraw[C::KPW];
+    half8 zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
+#define UMI_ISSUE(c_)                                                                                              \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < C::KPH; ++k)                                                        \
+            hraw[k] = pix[k] >= 0 ? *reinterpret_cast<const half8*>(xin + (long)pix[k] * ldx + (c_) * 16) : zero8; \
+        _Pragma("unroll") for (int k = 0; k < C::KPW; ++k)                                                        \
+            wraw[k] = (tap0 + k * TSTEP < 9)                                                                      \
+                          ? *reinterpret_cast<const half8*>(win + k * wstep + (long)(c_) * 2 * Co * 8) : zero8;   \
+    } while (0)
+
+    // fragment base addresses (bytes)
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int b_base = ((wm * 4) * HALO_W + lrow) * ROWB + lhalf * 16;               // + ((nt+dy)*34 + dx)*48
+    const int a_base = C::HB + (wn * 64 + lrow) * ROWB + lhalf * 16;                 // + (tap*BN + mt*32)*48
+
+    const int nchunks = Ci >> 4;
+    UMI_ISSUE(0);
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- registers -> (transform) -> LDS ----------------------------------------------------
+        if (HAS_TX) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = tx[c * 16 + q * 8 + j];
+#pragma unroll
+            for (int k = 0; k < C::KPH; ++k) {
+                if (pix[k] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hraw[k][j] = (half_t)umi_tx((float)hraw[k][j], t[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < C::KPH; ++k)
+            if ((tid >> 1) + 128 * k < C::HALO_PIX) *reinterpret_cast<half8*>(smem + hl_base + k * 128 * ROWB) = hraw[k];
+#pragma unroll
+        for (int k = 0; k < C::KPW; ++k)
+            if (tap0 + k * TSTEP < 9) *reinterpret_cast<half8*>(smem + wl_base + k * 128 * ROWB) = wraw[k];
+        __syncthreads();
+        if (c + 1 < nchunks) UMI_ISSUE(c + 1);
+
+        // ---- MFMA phase: 9 taps x (2 x 4) tiles -----------------------------------------------
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            half8 bf[6];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr)
+                bf[rr] = *reinterpret_cast<const half8*>(smem + b_base + (rr * HALO_W + dx) * ROWB);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                half8 af[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    af[mt] = *reinterpret_cast<const half8*>(smem + a_base + ((dy * 3 + dx) * BN + mt * 32) * ROWB);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt + dy], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc -> fp16 LDS tile [pixel][BN] ----------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int pix = (wm * 4 + nt) * 32 + lrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (half_t)acc[mt][nt][g * 4 + j];
+                const int co = wn * 64 + mt * 32 + g * 8 + lhalf * 4;
+                *reinterpret_cast<half4*>(smem + pix * C::ERS + co * 2) = h;
+            }
+        }
+    __syncthreads();
+
+    // coalesced 16-B stores of the tile
+    constexpr int PPR = BN / 8;                     // 16-B pieces per pixel row
+#pragma unroll 4
+    for (int i = tid; i < C::P * PPR; i += 256) {
+        int p = i / PPR, j = i - p * PPR;
+        int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
+        if (gy < H && gx < W) {
+            uint4 v = *reinterpret_cast<const uint4*>(smem + p * C::ERS + j * 16);
+            *reinterpret_cast<uint4*>(y + ((long)((long)n * H + gy) * W + gx) * ldy + c0 + j * 8) = v;
+        }
+    }
+
+    if (STATS) {
+        constexpr int SL = 256 / BN;               // pixel slices
+        const int col = tid % BN, sl = tid / BN;
+        float s = 0.f, s2 = 0.f;
+        for (int p = sl * (C::P / SL); p < (sl + 1) * (C::P / SL); ++p) {
+            int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
+            if (gy < H && gx < W) {
+                float v = (float)*reinterpret_cast<const half_t*>(smem + p * C::ERS + col * 2);
+                s += v;
+                s2 = fmaf(v, v, s2);
+            }
+        }
+        red[0][sl][col] = s;
+        red[1][sl][col] = s2;
+        __syncthreads();
+        if (tid < 2 * BN) {
+            int which = tid / BN, cc = tid % BN;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < SL; ++k) a += red[which][k][cc];
+            part[((long)pt * 2 + which) * Co + c0 + cc] = a;
+        }
+    }
+}
+
+template <int TH, int BN>
+int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H, int W,
+           int Ci, int Co, hipStream_t s) {
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = Co / BN;
+    const long nblk = (long)N * tiles_x * tiles_y * n_co;
+    dim3 grid((unsigned)nblk), block(256);
+#define GO(HT, ST)                                                                                               \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, ST>), grid, block, 0, s, (const half_t*)x, ldx,          \
+                       (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
+                       tiles_y, n_co)
+    if (tx) { if (part) GO(true, true); else GO(true, false); }
+    else    { if (part) GO(false, true); else GO(false, false); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+#undef UMI_ISSUE
+}  // namespace
+
+// Shapes the MFMA path takes; everything else goes to the generic kernel.
+bool umi_conv3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
+                         int ldx, int ldy, int in_dtype, int out_dtype, int flags, const float* bias) {
+    if (flags & (UMI_CONV_UPSAMPLE2 | UMI_CONV_FORCE_GENERIC)) return false;
+    if (in_dtype != UMI_F16 || out_dtype != UMI_F16 || bias) return false;
+    if (R != 3 || S != 3 || stride != 1 || pad != 1 || Ho != H || Wo != W) return false;
+    if (Ci % 16 || Co % 64 || ldx % 8 || ldy % 8) return false;
+    if ((long)N * H * W * (long)(ldx > ldy ? ldx : ldy) >= (1L << 40)) return false;
+    return true;
+}
+
+static int pick_th(int Co) { return (Co % 128 == 0) ? 8 : 16; }
+
+int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Co) {
+    const int th = pick_th(Co);
+    return N * ((W + 31) / 32) * ((H + th - 1) / th);
+}
+
+int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
+                     int N, int H, int W, int Ci, int Co, hipStream_t s) {
+    if (Co % 128 == 0) return launch<8, 128>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, s);
+    return launch<16, 64>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, s);
+}

@@ -112,8 +112,9 @@ class Tape:
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         if out is None:
             out = self.alloc(N, Ho, Wo, Co, device=a.raw.device)
-        wp = ops.pack_conv_fwd(weight.detach().float(), self.dtype)
-        part = ops.conv_fwd(a.raw, a.tx, wp, None, out, R, S, stride, pad, want_stats=self.training)
+        wf = weight.detach().float()
+        part = ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(wf, self.dtype, k8=bool(lay)), None, out,
+                            R, S, stride, pad, want_stats=self.training)
         if self.training:
             mom = bn.momentum if bn.momentum is not None else 0.1
             tx, rstd = ops.bn_finalize(part, Co, N * Ho * Wo, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
@@ -141,8 +142,8 @@ class Tape:
                     if stride != 1:
                         raise NotImplementedError("dgrad for strided conv_bn")
                     dx = self.alloc(N, H, W, Ci, device=out.device)
-                    wpd = ops.pack_conv_dgrad(weight.detach().float(), self.dtype)
-                    ops.conv_fwd(o.grad, None, wpd, None, dx, R, S, 1, R - 1 - pad)
+                    ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(wf, self.dtype, k8=bool(lay)), None, dx,
+                                 R, S, 1, R - 1 - pad)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o
@@ -172,8 +173,9 @@ class Tape:
                     self._set_pgrad(bias, gb)
                 if _wants_grad(a):
                     dx = self.alloc(N, H, W, Ci, device=out.device)
-                    wpd = ops.pack_conv_dgrad(weight.detach().float(), self.dtype)
-                    ops.conv_fwd(g, None, wpd, None, dx, R, S, 1, R - 1 - pad)
+                    wf = weight.detach().float()
+                    ops.conv_fwd(g, None, lambda lay: ops.pack_conv_dgrad(wf, self.dtype, k8=bool(lay)), None, dx,
+                                 R, S, 1, R - 1 - pad)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o

@@ -39,7 +39,7 @@ SIGNATURES = {
     "umi_conv_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "umi_conv_stat_rows": (c_int, [c_int] * 9),
+    "umi_conv_fwd_plan": (c_int, [c_int] * 15 + [c_void_p, c_void_p]),
     "umi_bn_finalize": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "umi_pool2_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -80,16 +80,16 @@ def pack_kn(src: torch.Tensor, T, K, N, st, sk, sn, flip_t, dtype, Kpad=None, Np
     return out
 
 
-def pack_conv_fwd(w: torch.Tensor, dtype, Kpad=None):
-    """OIHW -> [R*S][Ci][Co]."""
+def pack_conv_fwd(w: torch.Tensor, dtype, k8=False):
+    """OIHW -> [R*S][Ci][Co]  (k8: the MFMA kernels' [R*S][Ci/8][Co][8])."""
     Co, Ci, R, S = w.shape
-    return pack_kn(w, R * S, Ci, Co, 1, R * S, Ci * R * S, False, dtype, Kpad=Kpad)
+    return pack_kn(w, R * S, Ci, Co, 1, R * S, Ci * R * S, False, dtype, k8=k8)
 
 
-def pack_conv_dgrad(w: torch.Tensor, dtype):
+def pack_conv_dgrad(w: torch.Tensor, dtype, k8=False):
     """OIHW -> rotated/transposed [R*S][Co][Ci] so dgrad is a plain forward conv (stride 1)."""
     Co, Ci, R, S = w.shape
-    return pack_kn(w, R * S, Co, Ci, 1, Ci * R * S, R * S, True, dtype)
+    return pack_kn(w, R * S, Co, Ci, 1, Ci * R * S, R * S, True, dtype, k8=k8)
 
 
 def pack_convT_fwd(w: torch.Tensor, dtype):
@@ -105,9 +105,22 @@ def pack_convT_dgrad(w: torch.Tensor, dtype):
 
 
 # ------------------------------------------------------------------------------------------
+def conv_plan(x, y, R, S, stride, pad, flags=0, has_bias=False):
+    """(layout, stat_rows) libunetmi will use for this conv: layout 1 = weights must be packed k8."""
+    import ctypes
+    N, H, W, Ci, ldx = _nhwc(x)
+    _, _, _, Co, ldy = _nhwc(y)
+    lay, rows = ctypes.c_int(0), ctypes.c_int(0)
+    L.check(L.fn("umi_conv_fwd_plan")(N, H, W, Ci, Co, R, S, stride, pad, ldx, ldy, _dt(x), _dt(y), flags,
+                                      int(has_bias), ctypes.addressof(lay), ctypes.addressof(rows)),
+            "umi_conv_fwd_plan")
+    return lay.value, rows.value
+
+
 def conv_fwd(x, tx, wp, bias, y, R, S, stride, pad, want_stats=False, flags=0, up_offset=(0, 0)):
-    """y <- conv(tx(x), wp) [+ bias]; returns the stats-partials tensor when want_stats."""
-    _need_cuda(x, wp, y)
+    """y <- conv(tx(x), wp) [+ bias]; returns the stats-partials tensor when want_stats.
+    `wp` is a packed weight tensor or a callable(layout) -> packed tensor (see conv_plan)."""
+    _need_cuda(x, y)
     N, H, W, Ci, ldx = _nhwc(x)
     N2, oH, oW, Co, ldy = _nhwc(y)
     assert N2 == N
@@ -117,8 +130,12 @@ def conv_fwd(x, tx, wp, bias, y, R, S, stride, pad, want_stats=False, flags=0, u
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         assert (oH, oW) == (Ho, Wo), f"output view {oH}x{oW} != conv output {Ho}x{Wo}"
     part = None
+    layout, rows = conv_plan(x, y, R, S, stride, pad, flags, bias is not None)
+    if callable(wp):
+        wp = wp(layout)
+    elif layout != 0:
+        raise ValueError("this conv takes the MFMA path: pass a callable so the weights get the k8 packing")
     if want_stats:
-        rows = L.fn("umi_conv_stat_rows")(N, Ho, Wo, Ci, Co, R, S, _dt(x), flags)
         part = torch.empty(rows * 2 * Co, dtype=torch.float32, device=x.device)
     if tx is not None:
         assert tx.shape == (Ci, 4) and tx.dtype == torch.float32 and tx.is_contiguous()
