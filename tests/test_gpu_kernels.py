@@ -119,3 +119,61 @@ def test_wgrad_fast_path_vs_reference_and_generic(shape):
     scale = ref.abs().max().item()
     assert (res["generic"] - ref).abs().max().item() < 2e-3 * scale
     assert (res["fast"] - ref).abs().max().item() < 6e-3 * scale
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 6, 128, 64), (1, 16, 16, 64, 128), (2, 9, 7, 256, 128)])
+def test_conv_transpose_mfma_fwd_and_dgrad(shape):
+    """ConvTranspose2d(k2,s2) forward (scatter epilogue) and its data gradient (space-to-depth gather) on the
+    pointwise MFMA kernel vs torch and vs the generic kernels; destination is a padded channel slice."""
+    lib, ops = _gpu()
+    N, h, w, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, h, w, Cin, generator=g).half()
+    wt = (torch.randn(Cin, Cout, 2, 2, generator=g) * (1.0 / Cin) ** 0.5).half().float()
+    b = 0.1 * torch.randn(Cout, generator=g)
+    t = _tx(Cin, g)
+    a = _apply_tx(x.float(), t).permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(a, wt, b, stride=2).permute(0, 2, 3, 1)
+    Hd, Wd, oy, ox = 2 * h + 1, 2 * w + 2, 0, 1
+    wd = wt.to(DEV)
+    res = {}
+    for name, flags in (("mfma", lib.CONV_UPSAMPLE2), ("generic", lib.CONV_UPSAMPLE2 | lib.CONV_FORCE_GENERIC)):
+        buf = torch.zeros(N, Hd, Wd, 2 * Cout, device=DEV, dtype=torch.float16)
+        dest = buf[..., Cout:]
+        ops.conv_fwd(x.to(DEV), t.to(DEV), lambda l: ops.pack_convT_fwd(wd, torch.float16, k8=bool(l)), b.to(DEV), dest,
+                     2, 2, 2, 0, flags=flags, up_offset=(oy, ox))
+        assert ops.conv_plan(x.to(DEV), dest, 2, 2, 2, 0, flags)[0] == (1 if name == "mfma" else 0)
+        got = buf.float().cpu()
+        assert (got[..., :Cout] == 0).all()
+        inner = got[:, oy:oy + 2 * h, ox:ox + 2 * w, Cout:]
+        assert (inner - ref).abs().max().item() < 4e-3 * ref.abs().max().item(), name
+        mask = torch.ones(Hd, Wd, dtype=torch.bool)
+        mask[oy:oy + 2 * h, ox:ox + 2 * w] = False
+        assert (got[:, mask][..., Cout:] == 0).all()
+        res[name] = inner
+    # data gradient: stride-2 2x2 conv over d(up)
+    dup = (torch.randn(N, 2 * h, 2 * w, Cout, generator=g) * 0.1).half()
+    xr = torch.zeros(N, Cin, h, w, requires_grad=True)
+    F.conv_transpose2d(xr, wt, None, stride=2).backward(dup.float().permute(0, 3, 1, 2))
+    refd = xr.grad.permute(0, 2, 3, 1)
+    for name, flags in (("mfma", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        dx = torch.empty(N, h, w, Cin, device=DEV, dtype=torch.float16)
+        ops.conv_fwd(dup.to(DEV), None, lambda l: ops.pack_convT_dgrad(wd, torch.float16, k8=bool(l)), None, dx, 2, 2, 2, 0,
+                     flags=flags)
+        assert ops.conv_plan(dup.to(DEV), dx, 2, 2, 2, 0, flags)[0] == (1 if name == "mfma" else 0)
+        assert (dx.float().cpu() - refd).abs().max().item() < 4e-3 * refd.abs().max().item(), name
+
+
+def test_conv1x1_mfma_plain():
+    lib, ops = _gpu()
+    N, H, W, Ci, Co = 2, 13, 11, 192, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, H, W, Ci, generator=g).half()
+    wt = (torch.randn(Co, Ci, 1, 1, generator=g) * (1.0 / Ci) ** 0.5).half().float()
+    b = 0.1 * torch.randn(Co, generator=g)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt, b).permute(0, 2, 3, 1)
+    y = torch.empty(N, H, W, Co, device=DEV, dtype=torch.float16)
+    wd = wt.to(DEV)
+    ops.conv_fwd(x.to(DEV), None, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), b.to(DEV), y, 1, 1, 1, 0)
+    assert ops.conv_plan(x.to(DEV), y, 1, 1, 1, 0, 0, True)[0] == 1
+    assert (y.float().cpu() - ref).abs().max().item() < 3e-3 * ref.abs().max().item()

@@ -18,6 +18,12 @@ bool umi_conv3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int 
 int umi_conv3x3_mfma_stat_rows(int N, int Ho, int Wo, int Co);
 int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
                      int N, int H, int W, int Ci, int Co, hipStream_t s);
+// conv1x1_mfma.hip
+bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int ldy, int in_dtype,
+                         int out_dtype, int flags);
+int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y, int ldy,
+                     int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int off_h,
+                     int off_w, int out_H, int out_W, int flags, hipStream_t s);
 bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
                           int ldx, int lddy, int dtype, int flags, const void* txb);
 size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co);
@@ -37,7 +43,8 @@ extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int
     static const float one = 1.f;
     const bool mfma = umi_conv3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, in_dtype, out_dtype,
                                           flags, has_bias ? &one : nullptr);
-    if (layout) *layout = mfma ? 1 : 0;
+    const bool mfma1 = !mfma && umi_conv1x1_mfma_ok(Ci, Co, R, S, stride, pad, ldx, ldy, in_dtype, out_dtype, flags);
+    if (layout) *layout = (mfma || mfma1) ? 1 : 0;
     if (stat_rows) *stat_rows = mfma ? umi_conv3x3_mfma_stat_rows(N, H, W, Co) : umi_cdiv((long)N * Ho * Wo, 64);
     return UMI_OK;
 }
@@ -61,13 +68,24 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
         if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wp) & 15) return UMI_ERR_BADARG;
         return umi_conv3x3_mfma(x, ldx, tx, wp, y, ldy, stat_part, N, H, W, Ci, Co, (hipStream_t)stream);
     }
+    if (umi_conv1x1_mfma_ok(Ci, Co, R, S, stride, pad, ldx, ldy, in_dtype, out_dtype, flags)) {
+        if (stat_part) return UMI_ERR_UNSUPPORTED;      // no BatchNorm follows a pointwise conv on this path
+        if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wp) & 15) return UMI_ERR_BADARG;
+        return umi_conv1x1_mfma(x, ldx, tx, wp, bias, y, ldy, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, off_h, off_w,
+                                out_H, out_W, flags, (hipStream_t)stream);
+    }
     return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
                                 off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);
 }
 
 extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co, int R, int S, int dtype, int flags) {
-    (void)dtype; (void)flags;
-    return umi_conv_wgrad_generic_ws_bytes(N, Ho, Wo, Ci, Co, R, S);
+    // the call picks its path from more arguments than this query has; size for whichever needs more
+    size_t g = umi_conv_wgrad_generic_ws_bytes(N, Ho, Wo, Ci, Co, R, S);
+    if (umi_wgrad3x3_mfma_ok(N, Ho, Wo, Ci, Co, R, S, 1, 1, Ho, Wo, 8, 8, dtype, flags, nullptr)) {
+        size_t m = umi_wgrad3x3_mfma_ws_bytes(N, Ho, Wo, Ci, Co);
+        if (m > g) g = m;
+    }
+    return g;
 }
 
 extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, const void* txb,
@@ -76,7 +94,9 @@ extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const voi
                               size_t ws_bytes, umi_stream_t stream) {
     if (!x || !dy || !dW || !ws || N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || ldx < Ci || lddy < Co)
         return UMI_ERR_BADARG;
-    (void)flags;
+    if (umi_wgrad3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, lddy, dtype, flags, txb))
+        return umi_wgrad3x3_mfma(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes,
+                                 (hipStream_t)stream);
     return umi_conv_wgrad_generic(x, ldx, txa, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S,
                                   stride, pad, Ho, Wo, dtype, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -1,0 +1,248 @@
+// Pointwise convolutions on the gfx950 matrix cores (fp16 storage, fp32 accumulate):
+//   * plain 1x1 conv                                   y[p][co]        = sum_k  tx(x[p][k]) * w[k][co] (+ bias)
+//   * ConvTranspose2d(k=2,s=2) forward  (OUT_UPS)      y[2p+t][co]     = sum_k  tx(x[p][k]) * w_t[k][co] + bias
+//       = a 1x1 conv with 4*Cout outputs whose epilogue scatters channel block t to sub-pixel t
+//   * its data gradient                 (IN_S2D)       dx[p][ci]       = sum_t sum_k dy[2p+t][k] * w_t[k][ci]
+//       = a 1x1 conv whose K axis is the space-to-depth gather of the 4 sub-pixels
+// (reference Model.py:56-57,67 and the autograd of it; TransUNet's 1x1 convs / patch embedding reuse it).
+//
+// D[co][pixel] += W[co][k] * X[k][pixel] with v_mfma_f32_32x32x16_f16 (A = weights, B = pixels), same
+// structure as conv_mfma.hip with one tap: 256 threads = 4 waves, 2 workgroups per CU, tile = 256 linear
+// pixels x BN output channels, K staged in 64-channel chunks through registers (issue-early / write-late)
+// into LDS rows of 144 B (128 B data + 16 B pad = 9 slots, odd -> conflict-free ds_read_b128), consumer-side
+// BN+ReLU transform applied on the way.  Epilogue through an LDS tile for 16-B coalesced (scattered) stores.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int P = 256;        // pixels per workgroup tile
+constexpr int CK = 64;        // K chunk
+constexpr int ROWB = 144;     // LDS row bytes (64 halfs + 16 B pad)
+
+struct Geo {                  // geometry of the (optionally strided) source / destination tensors
+    int h, w;                 // the pixel grid the GEMM's M index runs over (N*h*w pixels)
+    int Hs, Ws, soy, sox;     // source tensor dims (+ window offset) ; for IN_S2D source pixel = (2y+dy+soy, 2x+dx+sox)
+    int Hd, Wd, doy, dox;     // destination dims (+ offset)          ; for OUT_UPS dest pixel = (2y+dy+doy, 2x+dx+dox)
+};
+
+template <int BN, bool IN_S2D, bool OUT_UPS, bool HAS_TX>
+__global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
+    const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
+    const float* __restrict__ bias, half_t* __restrict__ y, int ldy, long M, int Kc /*channels per tap of the source*/,
+    int Nc /*channels per tap of the destination*/, int n_co, Geo geo) {
+    constexpr int WN = BN / 64, WM = 4 / WN, NT = P / (32 * WM);
+    constexpr int XB = P * ROWB, WB = BN * ROWB;
+    constexpr int ERS = BN * 2 + 16, EB = P * ERS;
+    constexpr int SMEM = (XB + WB) > EB ? (XB + WB) : EB;
+    constexpr int KPX = P * 8 / 256;          // 8
+    constexpr int KPW = BN * 8 / 256;         // 4 or 2
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int cb = blockIdx.x % n_co;
+    const long m0 = (long)(blockIdx.x / n_co) * P;
+    const int c0 = cb * BN;
+    const int sub = tid & 7;
+
+    // ---- staging plan --------------------------------------------------------------------------------
+    long xoff[KPX];                           // element offset of this thread's pixel k in the source (tap 0), or -1
+#pragma unroll
+    for (int k = 0; k < KPX; ++k) {
+        long m = m0 + (tid >> 3) + 32 * k;
+        if (m < M) {
+            int n = (int)(m / ((long)geo.h * geo.w));
+            int r = (int)(m - (long)n * geo.h * geo.w);
+            int yy = r / geo.w, xx = r - yy * geo.w;
+            if (IN_S2D) { yy = 2 * yy + geo.soy; xx = 2 * xx + geo.sox; }
+            xoff[k] = ((long)((long)n * geo.Hs + yy) * geo.Ws + xx) * ldx + sub * 8;
+        } else xoff[k] = -1;
+    }
+    long woff[KPW];                           // element offset of weight row k (chunk 0)
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+        int cop = c0 + (tid >> 3) + 32 * k;   // output channel index in [0, taps_out * Nc)
+        int tap = OUT_UPS ? cop / Nc : 0;
+        int co = cop - tap * Nc;
+        // OUT_UPS : wp8 = [4][Kc/8][Nc][8]  (tap of the OUTPUT);   IN_S2D: wp8 = [4][Kc/8][Nc][8] (tap of the INPUT)
+        woff[k] = ((long)((long)tap * (Kc >> 3) + sub) * Nc + co) * 8;
+    }
+    const int xl = (tid >> 3) * ROWB + sub * 16;            // + k*32*ROWB
+    const int wl = XB + (tid >> 3) * ROWB + sub * 16;       // + k*32*ROWB
+
+    floatx16 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    half8 xraw[KPX], wraw[KPW];
+    half8 zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
+
+    const int chunks_per_tap = Kc / CK;
+    const int nchunks = IN_S2D ? 4 * chunks_per_tap : chunks_per_tap;
+#define UMI_ISSUE(c_)                                                                                              \
+    do {                                                                                                          \
+        const int cc = (c_);                                                                                      \
+        const int tap_in = IN_S2D ? cc / chunks_per_tap : 0;                                                      \
+        const int kc = cc - tap_in * chunks_per_tap;                                                              \
+        const long xadd = (long)kc * CK + (IN_S2D ? ((long)(tap_in >> 1) * geo.Ws + (tap_in & 1)) * ldx : 0);     \
+        const long wadd = ((long)tap_in * (Kc >> 3) + kc * 8) * Nc * 8;                                           \
+        _Pragma("unroll") for (int k = 0; k < KPX; ++k)                                                           \
+            xraw[k] = xoff[k] >= 0 ? *reinterpret_cast<const half8*>(x + xoff[k] + xadd) : zero8;                 \
+        _Pragma("unroll") for (int k = 0; k < KPW; ++k)                                                           \
+            wraw[k] = *reinterpret_cast<const half8*>(wp8 + woff[k] + wadd);                                      \
+    } while (0)
+
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int b_base = (wm * NT * 32 + lrow) * ROWB + lhalf * 16;         // + nt*32*ROWB + ks*32
+    const int a_base = XB + (wn * 64 + lrow) * ROWB + lhalf * 16;         // + mt*32*ROWB + ks*32
+
+    UMI_ISSUE(0);
+    for (int c = 0; c < nchunks; ++c) {
+        if (HAS_TX) {
+            const int kc = IN_S2D ? c % chunks_per_tap : c;
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = tx[kc * CK + sub * 8 + j];
+#pragma unroll
+            for (int k = 0; k < KPX; ++k)
+                if (xoff[k] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xraw[k][j] = (half_t)umi_tx((float)xraw[k][j], t[j]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < KPX; ++k) *reinterpret_cast<half8*>(smem + xl + k * 32 * ROWB) = xraw[k];
+#pragma unroll
+        for (int k = 0; k < KPW; ++k) *reinterpret_cast<half8*>(smem + wl + k * 32 * ROWB) = wraw[k];
+        __syncthreads();
+        if (c + 1 < nchunks) UMI_ISSUE(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < CK / 16; ++ks) {
+            half8 af[2], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const half8*>(smem + a_base + mt * 32 * ROWB + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const half8*>(smem + b_base + nt * 32 * ROWB + ks * 32);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef UMI_ISSUE
+
+    // ---- epilogue: (+bias) -> fp16 -> LDS tile [pixel][BN] -> 16-B stores (scattered per tap for OUT_UPS) -----
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int pix = (wm * NT + nt) * 32 + lrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wn * 64 + mt * 32 + g * 8 + lhalf * 4;
+                half4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[mt][nt][g * 4 + j];
+                    if (bias) {
+                        int cop = c0 + col + j;
+                        v += bias[OUT_UPS ? cop % Nc : cop];
+                    }
+                    h[j] = (half_t)v;
+                }
+                *reinterpret_cast<half4*>(smem + pix * ERS + col * 2) = h;
+            }
+        }
+    __syncthreads();
+    constexpr int PPR = BN / 8;
+    for (int i = tid; i < P * PPR; i += 256) {
+        int p = i / PPR, j = i - p * PPR;
+        long m = m0 + p;
+        if (m >= M) continue;
+        int n = (int)(m / ((long)geo.h * geo.w));
+        int r = (int)(m - (long)n * geo.h * geo.w);
+        int yy = r / geo.w, xx = r - yy * geo.w;
+        int cop = c0 + j * 8, co = cop;
+        if (OUT_UPS) {
+            int tap = cop / Nc;
+            co = cop - tap * Nc;
+            yy = 2 * yy + (tap >> 1) + geo.doy;
+            xx = 2 * xx + (tap & 1) + geo.dox;
+            if (yy < 0 || yy >= geo.Hd || xx < 0 || xx >= geo.Wd) continue;
+        }
+        uint4 v = *reinterpret_cast<const uint4*>(smem + p * ERS + j * 16);
+        *reinterpret_cast<uint4*>(y + ((long)((long)n * geo.Hd + yy) * geo.Wd + xx) * ldy + co) = v;
+    }
+}
+
+template <int BN>
+int launch(bool s2d, bool ups, const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y,
+           int ldy, long M, int Kc, int Nc, int Ntot, Geo geo, hipStream_t s) {
+    const int n_co = Ntot / BN;
+    const long nblk = ((M + P - 1) / P) * n_co;
+    dim3 grid((unsigned)nblk), block(256);
+#define GO(S2D, UPS, HT)                                                                                          \
+    hipLaunchKernelGGL((conv1x1_mfma_kernel<BN, S2D, UPS, HT>), grid, block, 0, s, (const half_t*)x, ldx,         \
+                       (const float4*)tx, (const half_t*)wp8, bias, (half_t*)y, ldy, M, Kc, Nc, n_co, geo)
+    if (s2d) { if (tx) GO(true, false, true); else GO(true, false, false); }
+    else if (ups) { if (tx) GO(false, true, true); else GO(false, true, false); }
+    else { if (tx) GO(false, false, true); else GO(false, false, false); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+}  // namespace
+
+// mode: 0 = plain 1x1, 1 = ConvT(2,2) forward (UMI_CONV_UPSAMPLE2), 2 = stride-2 2x2 conv (ConvT data gradient)
+int umi_conv1x1_mode(int R, int S, int stride, int pad, int flags) {
+    if (flags & UMI_CONV_UPSAMPLE2) return (R == 2 && S == 2) ? 1 : -1;
+    if (R == 1 && S == 1 && stride == 1 && pad == 0) return 0;
+    if (R == 2 && S == 2 && stride == 2 && pad == 0) return 2;
+    return -1;
+}
+
+bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int ldy, int in_dtype,
+                         int out_dtype, int flags) {
+    if (flags & UMI_CONV_FORCE_GENERIC) return false;
+    if (in_dtype != UMI_F16 || out_dtype != UMI_F16) return false;
+    const int mode = umi_conv1x1_mode(R, S, stride, pad, flags);
+    if (mode < 0) return false;
+    if (Ci % 64 || Co % 64 || ldx % 8 || ldy % 8) return false;
+    return true;
+}
+
+int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y, int ldy,
+                     int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int off_h,
+                     int off_w, int out_H, int out_W, int flags, hipStream_t s) {
+    const int mode = umi_conv1x1_mode(R, S, stride, pad, flags);
+    Geo geo;
+    long M;
+    int Kc = Ci, Nc = Co, Ntot = Co;
+    if (mode == 0) {
+        geo = Geo{H, W, H, W, 0, 0, H, W, 0, 0};
+        M = (long)N * H * W;
+    } else if (mode == 1) {            // input grid HxW -> output (out_H x out_W), 4 taps of Co channels each
+        geo = Geo{H, W, H, W, 0, 0, out_H, out_W, off_h, off_w};
+        M = (long)N * H * W;
+        Ntot = 4 * Co;
+    } else {                           // source is HxW, GEMM grid = Ho x Wo, K = 4 taps x Ci
+        geo = Geo{Ho, Wo, H, W, 0, 0, Ho, Wo, 0, 0};
+        M = (long)N * Ho * Wo;
+    }
+    if (Ntot % 128 == 0)
+        return launch<128>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, geo, s);
+    return launch<64>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, geo, s);
+}

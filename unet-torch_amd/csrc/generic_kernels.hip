@@ -643,6 +643,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     }
 }
 
+void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
+                             long s_t, float scale, hipStream_t st) {
+    long total = (long)RS * Ci * Co;
+    int g = (int)((total + 255) / 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
+}
+
 static void wgrad_generic_plan(long P, int Ci, int Co, int RS, int* splits, long* chunk) {
     long tiles = (long)umi_cdiv(Ci, 64) * umi_cdiv(Co, 64) * RS;
     long want = (2048 + tiles - 1) / tiles;          // aim for >= 2048 workgroups

@@ -1,0 +1,230 @@
+// conv3x3 (stride 1, pad 1) weight gradient on the gfx950 matrix cores, fp16 storage, fp32 accumulate.
+//
+//   dW[tap][ci][co] = sum over pixels  A[pixel + tap][ci] * dY[pixel][co],   A = tx(x) (BN+ReLU on load)
+//
+// is a GEMM whose contraction index is the PIXEL, while both tensors are NHWC (channel contiguous).  The
+// MFMA operands therefore need 8 consecutive pixels of one channel per lane -- a transpose of what is in
+// memory.  gfx950's ds_read_b64_tr_b16 does that transpose inside the LDS read: the tiles are staged
+// exactly as they sit in HBM ([pixel][32 channels], 64-byte rows -> the 4 pixel rows of one 32-lane half
+// hit 4 disjoint quarter bank-rows, conflict free) and each fragment is two transposing reads.
+//
+// Workgroup = 256 threads = 4 waves (2 ci-halves x 2 co-halves), 2 workgroups per CU.
+// Block tile = 64 ci x 64 co x all 9 taps; every wave holds 9 accumulator tiles (32 ci x 32 co per tap,
+// 144 registers).  K loop = pixel tiles of 4 rows x 32 pixels: the (4+2) x 34 input halo (64 ci) and the
+// 4 x 32 dY tile (64 co) are staged through registers (issue-early / write-late, transform applied on
+// the way), then per 16-pixel k-step and tap column the wave reuses 6 input-row fragments for the
+// 3 taps x 4 rows.  Split-K over pixel tiles; partial slabs [split][tap][ci][co] fp32 are reduced in
+// fixed order (deterministic) by wgrad_reduce_kernel into the parameter's own layout.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
+                             long s_t, float scale, hipStream_t st);
+
+namespace {
+
+constexpr int TR = 4;                    // image rows per pixel tile
+constexpr int HPIX = (TR + 2) * 34;      // halo pixels
+constexpr int PROW = 64;                 // LDS bytes per pixel row of one 32-channel chunk
+constexpr int A_CHUNK = HPIX * PROW;     // 13056
+constexpr int A_BYTES = 2 * A_CHUNK;     // 64 input channels
+constexpr int B_CHUNK = TR * 32 * PROW;  // 8192
+constexpr int B_BYTES = 2 * B_CHUNK;
+constexpr int SMEM = A_BYTES + B_BYTES;  // 42496
+constexpr int KPA = (HPIX * 8 + 255) / 256;   // 7 16-B pieces per thread for the halo
+constexpr int KPB = TR;                       // 4 pieces per thread for dY (piece k = image row k)
+
+__device__ __forceinline__ half8 tr_frag(const unsigned char* p) {
+    // two transposing reads: pixels +0..3 and +4..7 of this lane's channel
+    typedef __attribute__((address_space(3))) short4v* lds_ptr;
+    short4v r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    short4v r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * PROW));
+    half4 h0 = __builtin_bit_cast(half4, r0), h1 = __builtin_bit_cast(half4, r1);
+    return __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool HAS_TX>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
+    const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ dy, int lddy,
+    float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x, int tiles_y, int tiles_total,
+    int tiles_per_split, int n_co_t) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wci = wave >> 1, wco = wave & 1;
+    const int ci0 = (blockIdx.x / n_co_t) * 64, co0 = (blockIdx.x % n_co_t) * 64;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    int t_end = t_begin + tiles_per_split;
+    if (t_end > tiles_total) t_end = tiles_total;
+
+    // staging plan: A piece k -> halo pixel (tid>>3) + 32k, 8-channel group sub = tid & 7
+    const int sub = tid & 7;
+    int hyx[KPA];
+#pragma unroll
+    for (int k = 0; k < KPA; ++k) {
+        int hp = (tid >> 3) + 32 * k;
+        int hy = hp / 34, hx = hp - hy * 34;
+        hyx[k] = (hp < HPIX) ? (hy << 8) | hx : -1;
+    }
+    const int a_lds = (sub >> 2) * A_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;             // + k*32*PROW
+    const int b_lds = A_BYTES + (sub >> 2) * B_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;   // + k*32*PROW
+    const half_t* xin = x + ci0 + sub * 8;
+    const half_t* din = dy + co0 + sub * 8;
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    half8 araw[KPA], braw[KPB];
+    half8 zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
+    bool avalid[KPA];
+
+#define UMI_ISSUE(tile_)                                                                                         \
+    do {                                                                                                        \
+        const int tt = (tile_);                                                                                 \
+        const int n_ = tt / (tiles_x * tiles_y);                                                                \
+        const int rm_ = tt - n_ * tiles_x * tiles_y;                                                            \
+        const int ty0_ = (rm_ / tiles_x) * TR, tx0_ = (rm_ % tiles_x) * 32;                                     \
+        _Pragma("unroll") for (int k = 0; k < KPA; ++k) {                                                       \
+            int gy = ty0_ + (hyx[k] >> 8) - 1, gx = tx0_ + (hyx[k] & 255) - 1;                                  \
+            avalid[k] = hyx[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;                                  \
+            araw[k] = avalid[k] ? *reinterpret_cast<const half8*>(xin + ((long)((long)n_ * H + gy) * W + gx) * ldx) \
+                                : zero8;                                                                        \
+        }                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < KPB; ++k) {                                                       \
+            int gy = ty0_ + k, gx = tx0_ + (tid >> 3);                                                          \
+            braw[k] = (gy < H && gx < W)                                                                        \
+                          ? *reinterpret_cast<const half8*>(din + ((long)((long)n_ * H + gy) * W + gx) * lddy)  \
+                          : zero8;                                                                              \
+        }                                                                                                       \
+    } while (0)
+
+    // per-lane fragment addresses for the transposing reads (see file header)
+    const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+    const int frag_lane = (8 * (g >> 1) + lq) * PROW + (16 * (g & 1) + 4 * lp) * 2;
+    const unsigned char* a_frag = smem + wci * A_CHUNK + frag_lane;             // + ((rr*34) + 16*xh + dx) * PROW
+    const unsigned char* b_frag = smem + A_BYTES + wco * B_CHUNK + frag_lane;   // + (r*32 + 16*xh) * PROW
+
+    if (t_begin < t_end) UMI_ISSUE(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        if (HAS_TX) {
+            // re-read the 8 transform rows per tile (L1-resident) instead of pinning 32 registers across the
+            // MFMA phase; the opaque zero keeps the loads from being hoisted out of the tile loop
+            int opaque = 0;
+            asm volatile("" : "+v"(opaque));
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = tx[ci0 + sub * 8 + j + opaque];
+#pragma unroll
+            for (int k = 0; k < KPA; ++k)
+                if (avalid[k]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) araw[k][j] = (half_t)umi_tx((float)araw[k][j], t[j]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < KPA; ++k)
+            if (hyx[k] >= 0) *reinterpret_cast<half8*>(smem + a_lds + k * 32 * PROW) = araw[k];
+#pragma unroll
+        for (int k = 0; k < KPB; ++k) *reinterpret_cast<half8*>(smem + b_lds + k * 32 * PROW) = braw[k];
+        __syncthreads();
+        if (tile + 1 < t_end) UMI_ISSUE(tile + 1);
+
+#pragma unroll
+        for (int xh = 0; xh < 2; ++xh) {
+            half8 bfr[TR];
+#pragma unroll
+            for (int r = 0; r < TR; ++r) bfr[r] = tr_frag(b_frag + (r * 32 + 16 * xh) * PROW);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                half8 afr[TR + 2];
+#pragma unroll
+                for (int rr = 0; rr < TR + 2; ++rr) afr[rr] = tr_frag(a_frag + (rr * 34 + 16 * xh + dx) * PROW);
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int dyi = 0; dyi < 3; ++dyi)
+                        acc[dyi * 3 + dx] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[r + dyi], bfr[r], acc[dyi * 3 + dx], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#undef UMI_ISSUE
+
+    // partial slab: part[((z*9 + tap)*Ci + ci)*Co + co]
+    const int co = co0 + wco * 32 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            part[(((long)blockIdx.y * 9 + tap) * Ci + ci) * Co + co] = acc[tap][r];
+        }
+}
+
+void plan(int N, int H, int W, int Ci, int Co, int* tiles_x, int* tiles_y, int* tiles_total, int* splits, int* tps) {
+    *tiles_x = (W + 31) / 32;
+    *tiles_y = (H + TR - 1) / TR;
+    *tiles_total = N * (*tiles_x) * (*tiles_y);
+    const long pairs = (long)(Ci / 64) * (Co / 64);
+    long want = (1024 + pairs - 1) / pairs;             // ~2 resident workgroups per CU, two rounds
+    const long slab = 9L * Ci * Co * 4;
+    long cap = (96L << 20) / slab;                      // split-K slabs are written + re-read: bound that traffic
+    if (cap < 1) cap = 1;
+    if (pairs * cap < 512 && pairs < 512) cap = (512 + pairs - 1) / pairs;   // but never starve the chip
+    if (want > cap) want = cap;
+    if (want > *tiles_total) want = *tiles_total;
+    if (want < 1) want = 1;
+    *tps = (int)((*tiles_total + want - 1) / want);
+    *splits = (*tiles_total + *tps - 1) / *tps;
+}
+
+}  // namespace
+
+bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
+                          int ldx, int lddy, int dtype, int flags, const void* txb) {
+    if (flags & UMI_CONV_FORCE_GENERIC) return false;
+    if (dtype != UMI_F16 || txb) return false;
+    if (R != 3 || S != 3 || stride != 1 || pad != 1 || Ho != H || Wo != W) return false;
+    if (Ci % 64 || Co % 64 || ldx % 8 || lddy % 8) return false;
+    return true;
+}
+
+size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co) {
+    int tx_, ty_, tt, splits, tps;
+    plan(N, H, W, Ci, Co, &tx_, &ty_, &tt, &splits, &tps);
+    return (size_t)splits * 9 * Ci * Co * sizeof(float);
+}
+
+int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co,
+                      long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws,
+                      size_t ws_bytes, hipStream_t s) {
+    int tiles_x, tiles_y, tiles_total, splits, tps;
+    plan(N, H, W, Ci, Co, &tiles_x, &tiles_y, &tiles_total, &splits, &tps);
+    if (ws_bytes < (size_t)splits * 9 * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
+    if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
+    const int n_co_t = Co / 64;
+    dim3 grid((Ci / 64) * n_co_t, splits), block(256);
+    if (txa)
+        hipLaunchKernelGGL(wgrad3x3_mfma_kernel<true>, grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa,
+                           (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps,
+                           n_co_t);
+    else
+        hipLaunchKernelGGL(wgrad3x3_mfma_kernel<false>, grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa,
+                           (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps,
+                           n_co_t);
+    UMI_LAUNCH_CHECK();
+    umi_launch_wgrad_reduce((const float*)ws, splits, 9, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}

@@ -155,8 +155,9 @@ class Tape:
         assert Ca == Ci
         out = self.alloc(N, H + 2 * pad - R + 1, W + 2 * pad - S + 1, Co, dtype=out_dtype or self.dtype,
                          device=a.raw.device)
-        wp = ops.pack_conv_fwd(weight.detach().float(), self.dtype)
-        ops.conv_fwd(a.raw, a.tx, wp, bias.detach().float() if bias is not None else None, out, R, S, 1, pad)
+        wf0 = weight.detach().float()
+        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(wf0, self.dtype, k8=bool(lay)),
+                     bias.detach().float() if bias is not None else None, out, R, S, 1, pad)
         o = Act(out, None)
         if self.record:
             def bwd():
@@ -214,8 +215,9 @@ class Tape:
         oy, ox = dY // 2, dX // 2
         if dY or dX:
             dest.zero_()
-        wp = ops.pack_convT_fwd(weight.detach().float(), self.dtype)
-        ops.conv_fwd(a.raw, a.tx, wp, bias.detach().float() if bias is not None else None, dest, 2, 2, 2, 0,
+        wf = weight.detach().float()
+        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_convT_fwd(wf, self.dtype, k8=bool(lay)),
+                     bias.detach().float() if bias is not None else None, dest, 2, 2, 2, 0,
                      flags=L.CONV_UPSAMPLE2, up_offset=(oy, ox))
         o = Act(dest, None)
         if self.record:
@@ -236,8 +238,8 @@ class Tape:
                 self._set_pgrad(weight, gw)
                 if _wants_grad(a):
                     dx = self.alloc(N, h, w, Cin, device=dest.device)
-                    wpd = ops.pack_convT_dgrad(weight.detach().float(), self.dtype)
-                    ops.conv_fwd(g, None, wpd, None, dx, 2, 2, 2, 0)
+                    ops.conv_fwd(g, None, lambda lay: ops.pack_convT_dgrad(wf, self.dtype, k8=bool(lay)), None, dx,
+                                 2, 2, 2, 0)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o

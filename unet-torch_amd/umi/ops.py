@@ -92,16 +92,16 @@ def pack_conv_dgrad(w: torch.Tensor, dtype, k8=False):
     return pack_kn(w, R * S, Co, Ci, 1, Ci * R * S, R * S, True, dtype, k8=k8)
 
 
-def pack_convT_fwd(w: torch.Tensor, dtype):
+def pack_convT_fwd(w: torch.Tensor, dtype, k8=False):
     """ConvTranspose2d [Cin][Cout][2][2] -> [4][Cin][Cout]."""
     Cin, Cout = w.shape[:2]
-    return pack_kn(w, 4, Cin, Cout, 1, Cout * 4, 4, False, dtype)
+    return pack_kn(w, 4, Cin, Cout, 1, Cout * 4, 4, False, dtype, k8=k8)
 
 
-def pack_convT_dgrad(w: torch.Tensor, dtype):
+def pack_convT_dgrad(w: torch.Tensor, dtype, k8=False):
     """ConvTranspose2d [Cin][Cout][2][2] -> [4][Cout][Cin] (stride-2 2x2 conv over d(up))."""
     Cin, Cout = w.shape[:2]
-    return pack_kn(w, 4, Cout, Cin, 1, 4, Cout * 4, False, dtype)
+    return pack_kn(w, 4, Cout, Cin, 1, 4, Cout * 4, False, dtype, k8=k8)
 
 
 # ------------------------------------------------------------------------------------------
