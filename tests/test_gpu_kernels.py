@@ -177,3 +177,51 @@ def test_conv1x1_mfma_plain():
     ops.conv_fwd(x.to(DEV), None, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), b.to(DEV), y, 1, 1, 1, 0)
     assert ops.conv_plan(x.to(DEV), y, 1, 1, 1, 0, 0, True)[0] == 1
     assert (y.float().cpu() - ref).abs().max().item() < 3e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("cin", [1, 3])
+def test_stem_and_head_fast_paths(cin):
+    """First conv (Ci <= 4) forward + stats + wgrad and the OutConv head (fwd fp32, dgrad, wgrad) vs the generic kernels."""
+    lib, ops = _gpu()
+    N, H, W, C, ncls = 2, 37, 29, 64, 2 if cin == 1 else 4
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(N, H, W, cin, generator=g).half().to(DEV)
+    w = (torch.randn(C, cin, 3, 3, generator=g) * 0.3).to(DEV)
+    outs = {}
+    for name, flags in (("fast", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        y = torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+        part = ops.conv_fwd(x, None, lambda l: ops.pack_conv_fwd(w, torch.float16, k8=bool(l)), None, y, 3, 3, 1, 1,
+                            want_stats=True, flags=flags)
+        gw = torch.empty(C, cin, 3, 3, device=DEV)
+        dy = (torch.randn(N, H, W, C, generator=g) * 0.1).half().to(DEV)
+        ops.conv_wgrad(x, None, dy, None, gw, cin * 9, 9, 1, 0.25, 3, 3, 1, 1, flags=flags)
+        outs[name] = (y.float().cpu(), part.view(-1, 2, C).sum(0).cpu(), gw.cpu())
+        g = torch.Generator().manual_seed(cin)          # same dy for both arms
+        _ = torch.randn(N, H, W, cin, generator=g); _ = torch.randn(C, cin, 3, 3, generator=g)
+    (yf, sf, gf), (yg, sg, gg) = outs["fast"], outs["generic"]
+    assert (yf - yg).abs().max().item() <= 2e-3 * yg.abs().max().item()
+    torch.testing.assert_close(sf, sg, rtol=2e-3, atol=1e-2)
+    assert (gf - gg).abs().max().item() < 2e-3 * gg.abs().max().item()
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.half().float().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    assert (yf - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+
+    # head
+    a = torch.randn(N, H, W, C, generator=g).half().to(DEV)
+    t = _tx(C, g).to(DEV)
+    wo = (torch.randn(ncls, C, 1, 1, generator=g) * 0.2).to(DEV)
+    b = (0.1 * torch.randn(ncls, generator=g)).to(DEV)
+    dl = (torch.randn(N, H, W, ncls, generator=g) * 0.05).half().to(DEV)
+    res = {}
+    for name, flags in (("fast", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        logits = torch.empty(N, H, W, ncls, device=DEV, dtype=torch.float32)
+        ops.conv_fwd(a, t, lambda l: ops.pack_conv_fwd(wo, torch.float16, k8=bool(l)), b, logits, 1, 1, 1, 0, flags=flags)
+        da = torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+        ops.conv_fwd(dl, None, lambda l: ops.pack_conv_dgrad(wo, torch.float16, k8=bool(l)), None, da, 1, 1, 1, 0, flags=flags)
+        gwo = torch.empty(ncls, C, 1, 1, device=DEV)
+        ops.conv_wgrad(a, t, dl, None, gwo, C, 1, 1, 2.0, 1, 1, 1, 0, flags=flags)
+        res[name] = (logits.cpu(), da.float().cpu(), gwo.cpu())
+    for f, gnr in zip(res["fast"], res["generic"]):
+        assert (f - gnr).abs().max().item() < 2e-3 * gnr.abs().max().item()
+    act = _apply_tx(a.float().cpu(), t.cpu())
+    ref = F.conv2d(act.permute(0, 3, 1, 2), wo.half().float().cpu(), b.cpu()).permute(0, 2, 3, 1)
+    assert (res["fast"][0] - ref).abs().max().item() < 1e-3 * ref.abs().max().item()

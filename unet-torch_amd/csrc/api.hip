@@ -24,6 +24,26 @@ bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int 
 int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y, int ldy,
                      int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int off_h,
                      int off_w, int out_H, int out_W, int flags, hipStream_t s);
+// stem_head.hip
+bool umi_stem_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldy, int in_dtype, int out_dtype, int flags,
+                     const float* bias);
+int umi_stem_stat_rows(int N, int H, int W);
+int umi_stem_fwd(const void* x, int ldx, const void* tx, const void* wp, void* y, int ldy, float* part, int N, int H, int W,
+                 int Ci, int Co, hipStream_t s);
+bool umi_stem_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int lddy, int dtype, int flags, const void* txb);
+size_t umi_stem_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
+int umi_stem_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
+                   long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s);
+bool umi_head_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int in_dtype, int out_dtype, int flags);
+int umi_head_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy, long P,
+                 int Ci, int Co, hipStream_t s);
+bool umi_smallk_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldy, int in_dtype, int out_dtype, int flags,
+                       const void* tx, const float* bias);
+int umi_smallk_fwd(const void* x, int ldx, const void* wp, void* y, int ldy, long P, int Ci, int Co, hipStream_t s);
+bool umi_head_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int dtype, int flags, const void* txb);
+size_t umi_head_wgrad_ws_bytes(long P, int Ci, int Co);
+int umi_head_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
+                   long s_t, float out_scale, long P, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s);
 bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
                           int ldx, int lddy, int dtype, int flags, const void* txb);
 size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co);
@@ -45,7 +65,11 @@ extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int
                                           flags, has_bias ? &one : nullptr);
     const bool mfma1 = !mfma && umi_conv1x1_mfma_ok(Ci, Co, R, S, stride, pad, ldx, ldy, in_dtype, out_dtype, flags);
     if (layout) *layout = (mfma || mfma1) ? 1 : 0;
-    if (stat_rows) *stat_rows = mfma ? umi_conv3x3_mfma_stat_rows(N, H, W, Co) : umi_cdiv((long)N * Ho * Wo, 64);
+    const bool stem = !mfma && !mfma1 &&
+                      umi_stem_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, has_bias ? &one : nullptr);
+    if (stat_rows)
+        *stat_rows = mfma ? umi_conv3x3_mfma_stat_rows(N, H, W, Co)
+                          : (stem ? umi_stem_stat_rows(N, H, W) : umi_cdiv((long)N * Ho * Wo, 64));
     return UMI_OK;
 }
 
@@ -74,6 +98,12 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
         return umi_conv1x1_mfma(x, ldx, tx, wp, bias, y, ldy, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, off_h, off_w,
                                 out_H, out_W, flags, (hipStream_t)stream);
     }
+    if (umi_stem_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, bias))
+        return umi_stem_fwd(x, ldx, tx, wp, y, ldy, stat_part, N, H, W, Ci, Co, (hipStream_t)stream);
+    if (!stat_part && umi_head_fwd_ok(Ci, Co, R, S, stride, pad, ldx, in_dtype, out_dtype, flags))
+        return umi_head_fwd(x, ldx, tx, wp, bias, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
+    if (!stat_part && umi_smallk_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias))
+        return umi_smallk_fwd(x, ldx, wp, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
     return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
                                 off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);
 }
@@ -83,6 +113,14 @@ extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co,
     size_t g = umi_conv_wgrad_generic_ws_bytes(N, Ho, Wo, Ci, Co, R, S);
     if (umi_wgrad3x3_mfma_ok(N, Ho, Wo, Ci, Co, R, S, 1, 1, Ho, Wo, 8, 8, dtype, flags, nullptr)) {
         size_t m = umi_wgrad3x3_mfma_ws_bytes(N, Ho, Wo, Ci, Co);
+        if (m > g) g = m;
+    }
+    if (umi_stem_wgrad_ok(Ci, Co, R, S, 1, 1, 8, dtype, flags, nullptr)) {
+        size_t m = umi_stem_wgrad_ws_bytes(N, Ho, Wo, Ci, Co);
+        if (m > g) g = m;
+    }
+    if (umi_head_wgrad_ok(Ci, Co, R, S, 1, 0, 8, dtype, flags, nullptr)) {
+        size_t m = umi_head_wgrad_ws_bytes((long)N * Ho * Wo, Ci, Co);
         if (m > g) g = m;
     }
     return g;
@@ -97,6 +135,12 @@ extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const voi
     if (umi_wgrad3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, lddy, dtype, flags, txb))
         return umi_wgrad3x3_mfma(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes,
                                  (hipStream_t)stream);
+    if (umi_stem_wgrad_ok(Ci, Co, R, S, stride, pad, lddy, dtype, flags, txb))
+        return umi_stem_wgrad(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes,
+                              (hipStream_t)stream);
+    if (umi_head_wgrad_ok(Ci, Co, R, S, stride, pad, ldx, dtype, flags, txb))
+        return umi_head_wgrad(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, (long)N * H * W, Ci, Co, ws,
+                              ws_bytes, (hipStream_t)stream);
     return umi_conv_wgrad_generic(x, ldx, txa, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S,
                                   stride, pad, Ho, Wo, dtype, ws, ws_bytes, (hipStream_t)stream);
 }

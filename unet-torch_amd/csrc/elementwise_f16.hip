@@ -1,0 +1,243 @@
+// HBM-bound fp16 kernels, vectorised to 16 B per lane (8 channels): BatchNorm+ReLU backward (reduce / apply)
+// and MaxPool2d(2) forward / backward.  Taken when C % 8 == 0, pixel strides % 8 == 0, 16-B aligned bases
+// and (C/8) divides 256; anything else stays on the scalar generic kernels.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int RPB = 512;       // pixel rows per stage-1 block of the BN-backward reduction
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- BN + ReLU backward, stage 1: per-block partial sums of dz and dz*xhat ------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce1_v8(const half_t* __restrict__ da, int ldda,
+                                                         const half_t* __restrict__ y, int ldy,
+                                                         const float4* __restrict__ tx, const float* __restrict__ rstd,
+                                                         float* __restrict__ ws, long M, int C) {
+    __shared__ float red[2][256][9];               // [which][thread][8 channels] (+1 pad: conflict-free column sums)
+    const int tid = threadIdx.x;
+    const int G = C >> 3;                          // channel groups of 8; G divides 256
+    const int PL = 256 / G;
+    const int cg = tid % G, pl = tid / G;
+    const long r0 = (long)blockIdx.x * RPB;
+    long r1 = r0 + RPB;
+    if (r1 > M) r1 = M;
+    float4 t[8];
+    float rs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { t[j] = tx[cg * 8 + j]; rs[j] = rstd[cg * 8 + j]; }
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (long r = r0 + pl; r < r1; r += PL) {
+        half8 yv = *reinterpret_cast<const half8*>(y + r * ldy + cg * 8);
+        half8 gv = *reinterpret_cast<const half8*>(da + r * ldda + cg * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float yy = (float)yv[j];
+            float z = umi_tx_pre(yy, t[j]);
+            float dz = z > t[j].w ? (float)gv[j] : 0.f;
+            s[j] += dz;
+            q[j] = fmaf(dz, (yy - t[j].x) * rs[j], q[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][tid][j] = s[j]; red[1][tid][j] = q[j]; }
+    __syncthreads();
+    // thread (which, c) sums the PL pixel lanes of its channel in fixed order
+    for (int i = tid; i < 2 * C; i += 256) {
+        int which = i / C, c = i - which * C;
+        int g = c >> 3, j = c & 7;
+        float a = 0.f;
+        for (int k = 0; k < PL; ++k) a += red[which][k * G + g][j];
+        ws[((long)blockIdx.x * 2 + which) * C + c] = a;
+    }
+}
+
+// ---- BN + ReLU backward, stage 3: dy = gamma*rstd * (dz - sum_dz/M - xhat*sum_dzx/M), in place ---------------
+__global__ __launch_bounds__(256) void bn_bwd_apply_v8(half_t* __restrict__ da, int ldda, const half_t* __restrict__ y,
+                                                       int ldy, const float4* __restrict__ tx,
+                                                       const float* __restrict__ rstd,
+                                                       const float* __restrict__ sum_dz,
+                                                       const float* __restrict__ sum_dzx, long M, int C) {
+    const int G = C >> 3;
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;     // gridDim*256 is a multiple of G => cg fixed per thread
+    const int cg = (int)(gt % G);
+    const long stride_rows = ((long)gridDim.x * 256) / G;
+    const float invM = 1.f / (float)M;
+    float4 t[8];
+    float rs[8], c1[8], c2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int c = cg * 8 + j;
+        t[j] = tx[c];
+        rs[j] = rstd[c];
+        c1[j] = sum_dz[c] * invM;
+        c2[j] = sum_dzx[c] * invM;
+    }
+    for (long r = gt / G; r < M; r += stride_rows) {
+        half8 yv = *reinterpret_cast<const half8*>(y + r * ldy + cg * 8);
+        half8 gv = *reinterpret_cast<const half8*>(da + r * ldda + cg * 8);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float yy = (float)yv[j];
+            float z = umi_tx_pre(yy, t[j]);
+            float dz = z > t[j].w ? (float)gv[j] : 0.f;
+            float xh = (yy - t[j].x) * rs[j];
+            o[j] = (half_t)(t[j].y * (dz - c1[j] - xh * c2[j]));
+        }
+        *reinterpret_cast<half8*>(da + r * ldda + cg * 8) = o;
+    }
+}
+
+// ---- MaxPool2d(2) forward on the transformed tensor -------------------------------------------------------
+template <bool HAS_TX>
+__global__ __launch_bounds__(256) void pool2_fwd_v8(const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx,
+                                                    half_t* __restrict__ y, int ldy, int N, int H, int W, int C) {
+    const int G = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);
+    const long stride_p = ((long)gridDim.x * 256) / G;
+    const long P = (long)N * Ho * Wo;
+    float4 t[8];
+    if (HAS_TX) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = tx[cg * 8 + j];
+    }
+    for (long p = gt / G; p < P; p += stride_p) {
+        int wo = (int)(p % Wo);
+        long r = p / Wo;
+        int ho = (int)(r % Ho);
+        int n = (int)(r / Ho);
+        const half_t* base = x + ((long)((long)n * H + 2 * ho) * W + 2 * wo) * ldx + cg * 8;
+        half8 v[4];
+        v[0] = *reinterpret_cast<const half8*>(base);
+        v[1] = *reinterpret_cast<const half8*>(base + ldx);
+        v[2] = *reinterpret_cast<const half8*>(base + (long)W * ldx);
+        v[3] = *reinterpret_cast<const half8*>(base + (long)W * ldx + ldx);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float f = (float)v[d][j];
+                if (HAS_TX) f = umi_tx(f, t[j]);
+                m = f > m ? f : m;
+            }
+            o[j] = (half_t)m;
+        }
+        *reinterpret_cast<half8*>(y + p * ldy + cg * 8) = o;
+    }
+}
+
+// ---- MaxPool2d(2) backward: first arg-max of tx(x) gets dpool (even H and W only) -----------------------------
+template <bool HAS_TX, bool ACC>
+__global__ __launch_bounds__(256) void pool2_bwd_v8(const half_t* __restrict__ dp, int lddp, const half_t* __restrict__ x,
+                                                    int ldx, const float4* __restrict__ tx, half_t* __restrict__ da,
+                                                    int ldda, int N, int H, int W, int C) {
+    const int G = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);
+    const long stride_p = ((long)gridDim.x * 256) / G;
+    const long P = (long)N * Ho * Wo;
+    float4 t[8];
+    if (HAS_TX) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = tx[cg * 8 + j];
+    }
+    for (long p = gt / G; p < P; p += stride_p) {
+        int wo = (int)(p % Wo);
+        long r = p / Wo;
+        int ho = (int)(r % Ho);
+        int n = (int)(r / Ho);
+        const long pix = ((long)((long)n * H + 2 * ho) * W + 2 * wo);
+        const long off[4] = {0, 1, (long)W, (long)W + 1};
+        half8 v[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = *reinterpret_cast<const half8*>(x + (pix + off[d]) * ldx + cg * 8);
+        half8 g = *reinterpret_cast<const half8*>(dp + p * lddp + cg * 8);
+        half8 o[4];
+        if (ACC) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = *reinterpret_cast<const half8*>(da + (pix + off[d]) * ldda + cg * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m = -INFINITY;
+            int best = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float f = (float)v[d][j];
+                if (HAS_TX) f = umi_tx(f, t[j]);
+                if (d == 0 || f > m) { m = f; best = d; }
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float add = (d == best) ? (float)g[j] : 0.f;
+                o[d][j] = ACC ? (half_t)((float)o[d][j] + add) : (half_t)add;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) *reinterpret_cast<half8*>(da + (pix + off[d]) * ldda + cg * 8) = o[d];
+    }
+}
+
+bool vec_ok(int C, int lda, int ldb, const void* a, const void* b) {
+    if (C % 8 || lda % 8 || ldb % 8) return false;
+    const int G = C / 8;
+    if (G > 256 || 256 % G) return false;
+    return al16(a) && al16(b);
+}
+
+int grid_for(long items) {
+    long g = (items + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+int umi_bn_bwd_rpb_f16v() { return RPB; }
+
+bool umi_bn_bwd_reduce1_f16v(const void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd, float* ws,
+                             long M, int C, hipStream_t s) {
+    if (!vec_ok(C, ldda, ldy, da, y)) return false;
+    int rows = (int)((M + RPB - 1) / RPB);
+    hipLaunchKernelGGL(bn_bwd_reduce1_v8, dim3(rows), dim3(256), 0, s, (const half_t*)da, ldda, (const half_t*)y, ldy,
+                       (const float4*)tx, rstd, ws, M, C);
+    return true;
+}
+
+bool umi_bn_bwd_apply_f16v(void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd,
+                           const float* sum_dz, const float* sum_dzx, long M, int C, hipStream_t s) {
+    if (!vec_ok(C, ldda, ldy, da, y)) return false;
+    hipLaunchKernelGGL(bn_bwd_apply_v8, dim3(grid_for(M * (C / 8))), dim3(256), 0, s, (half_t*)da, ldda, (const half_t*)y, ldy,
+                       (const float4*)tx, rstd, sum_dz, sum_dzx, M, C);
+    return true;
+}
+
+bool umi_pool2_fwd_f16v(const void* x, int ldx, const void* tx, void* y, int ldy, int N, int H, int W, int C,
+                        hipStream_t s) {
+    if (!vec_ok(C, ldx, ldy, x, y)) return false;
+    int grid = grid_for((long)N * (H / 2) * (W / 2) * (C / 8));
+    if (tx) hipLaunchKernelGGL(pool2_fwd_v8<true>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)tx, (half_t*)y, ldy, N, H, W, C);
+    else hipLaunchKernelGGL(pool2_fwd_v8<false>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)tx, (half_t*)y, ldy, N, H, W, C);
+    return true;
+}
+
+bool umi_pool2_bwd_f16v(const void* dp, int lddp, const void* x, int ldx, const void* tx, void* da, int ldda,
+                        int accumulate, int N, int H, int W, int C, hipStream_t s) {
+    if ((H | W) & 1) return false;                        // odd tails stay on the generic kernel
+    if (!vec_ok(C, ldx, ldda, x, da) || lddp % 8 || !al16(dp)) return false;
+    int grid = grid_for((long)N * (H / 2) * (W / 2) * (C / 8));
+#define GO(T, A) hipLaunchKernelGGL((pool2_bwd_v8<T, A>), dim3(grid), dim3(256), 0, s, (const half_t*)dp, lddp, (const half_t*)x, ldx, (const float4*)tx, (half_t*)da, ldda, N, H, W, C)
+    if (tx) { if (accumulate) GO(true, true); else GO(true, false); }
+    else    { if (accumulate) GO(false, true); else GO(false, false); }
+#undef GO
+    return true;
+}

@@ -4,6 +4,17 @@
 // 256-thread workgroups = 4 waves, float4 LDS reads).
 #include "common.h"
 
+// elementwise_f16.hip: 16-B vectorised fp16 fast paths (return false when the shape does not qualify)
+int umi_bn_bwd_rpb_f16v();
+bool umi_bn_bwd_reduce1_f16v(const void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd, float* ws,
+                             long M, int C, hipStream_t s);
+bool umi_bn_bwd_apply_f16v(void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd,
+                           const float* sum_dz, const float* sum_dzx, long M, int C, hipStream_t s);
+bool umi_pool2_fwd_f16v(const void* x, int ldx, const void* tx, void* y, int ldy, int N, int H, int W, int C,
+                        hipStream_t s);
+bool umi_pool2_bwd_f16v(const void* dp, int lddp, const void* x, int ldx, const void* tx, void* da, int ldda,
+                        int accumulate, int N, int H, int W, int C, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------
@@ -344,6 +355,10 @@ __global__ void pool2_bwd_kernel(const T* __restrict__ dp, int lddp, const T* __
 extern "C" int umi_pool2_fwd(const void* x, int ldx, const void* tx, void* y, int ldy, int N, int H, int W, int C,
                              int dtype, umi_stream_t stream) {
     if (N <= 0 || H < 2 || W < 2 || C <= 0) return UMI_ERR_BADARG;
+    if (dtype == UMI_F16 && umi_pool2_fwd_f16v(x, ldx, tx, y, ldy, N, H, W, C, (hipStream_t)stream)) {
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     long total = (long)N * (H / 2) * (W / 2) * ((C + 3) / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 16384) grid = 16384;
@@ -357,6 +372,11 @@ extern "C" int umi_pool2_fwd(const void* x, int ldx, const void* tx, void* y, in
 extern "C" int umi_pool2_bwd(const void* dpool, int lddp, const void* x, int ldx, const void* tx, void* da, int ldda,
                              int accumulate, int N, int H, int W, int C, int dtype, umi_stream_t stream) {
     if (N <= 0 || H < 2 || W < 2 || C <= 0) return UMI_ERR_BADARG;
+    if (dtype == UMI_F16 &&
+        umi_pool2_bwd_f16v(dpool, lddp, x, ldx, tx, da, ldda, accumulate, N, H, W, C, (hipStream_t)stream)) {
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * ((C + 3) / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 16384) grid = 16384;
@@ -471,6 +491,13 @@ extern "C" int umi_bn_bwd_reduce(const void* da, int ldda, const void* y, int ld
     if (ws_bytes < umi_bn_bwd_ws_bytes(M, C)) return UMI_ERR_WORKSPACE;
     int rows = umi_cdiv(M, BNB_RPB);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F16 && umi_bn_bwd_reduce1_f16v(da, ldda, y, ldy, tx, rstd, (float*)ws, M, C, s)) {
+        UMI_LAUNCH_CHECK();
+        rows = umi_cdiv(M, umi_bn_bwd_rpb_f16v());
+        hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, rows, C, sum_dz, sum_dzx, 1.f);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     if (dtype == UMI_F32) hipLaunchKernelGGL(bn_bwd_reduce1_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)da, ldda, (const float*)y, ldy, (const float4*)tx, rstd, (float*)ws, M, C);
     else if (dtype == UMI_F16) hipLaunchKernelGGL(bn_bwd_reduce1_kernel<half_t>, dim3(rows), dim3(256), 0, s, (const half_t*)da, ldda, (const half_t*)y, ldy, (const float4*)tx, rstd, (float*)ws, M, C);
     else return UMI_ERR_BADARG;
@@ -488,6 +515,10 @@ extern "C" int umi_bn_bwd_apply(void* da, int ldda, const void* y, int ldy, cons
     int grid = (int)((total + 255) / 256);
     if (grid > 16384) grid = 16384;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F16 && umi_bn_bwd_apply_f16v(da, ldda, y, ldy, tx, rstd, sum_dz, sum_dzx, M, C, s)) {
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     if (dtype == UMI_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)da, ldda, (const float*)y, ldy, (const float4*)tx, rstd, sum_dz, sum_dzx, M, C);
     else if (dtype == UMI_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (half_t*)da, ldda, (const half_t*)y, ldy, (const float4*)tx, rstd, sum_dz, sum_dzx, M, C);
     else return UMI_ERR_BADARG;

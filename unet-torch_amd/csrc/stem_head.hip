@@ -1,0 +1,368 @@
+// HBM-bound ends of the network (fp16 storage), where matrix cores cannot help:
+//   * stem : the first 3x3 conv, Ci <= 4 (reference Model.py:111 `inc` with n_channels 1 or 3): forward with the
+//            BatchNorm-statistics epilogue, and its weight gradient.  Arithmetic intensity ~9 FLOP/B.
+//   * head : OutConv 1x1 with n_classes <= 8 outputs (reference Model.py:86-92): forward (fp32 logits, bias,
+//            BN+ReLU of the producer applied on load), data gradient (K = n_classes) and weight gradient.
+// One thread = one pixel x 8 channels (16-B accesses, 8 lanes per 128-B line); per-channel reductions go
+// through registers -> LDS -> one deterministic partial row per workgroup.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
+                             long s_t, float scale, hipStream_t st);
+
+namespace {
+
+constexpr int STEM_PPB = 1024;       // pixels per workgroup (stem forward)
+constexpr int WG_PPB = 4096;         // pixels per workgroup (weight-gradient kernels)
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------
+template <int CI>
+__global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const half_t* __restrict__ x, int ldx,
+                                                          const float4* __restrict__ tx, const half_t* __restrict__ wp,
+                                                          half_t* __restrict__ y, int ldy, float* __restrict__ part,
+                                                          int N, int H, int W, int Co) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [9*CI][Co] weights, then reduction scratch
+    const int tid = threadIdx.x;
+    const int G = Co >> 3, PL = 256 / G;
+    const int cg = tid % G, pl = tid / G;
+    float* wsm = sm;
+    for (int i = tid; i < 9 * CI * Co; i += 256) wsm[i] = (float)wp[i];
+    __syncthreads();
+    const long P = (long)N * H * W;
+    const long p0 = (long)blockIdx.x * STEM_PPB;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (long p = p0 + pl; p < p0 + STEM_PPB && p < P; p += PL) {
+        int n = (int)(p / ((long)H * W));
+        int r = (int)(p - (long)n * H * W);
+        int yy = r / W, xx = r - yy * W;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            int hi = yy + tap / 3 - 1, wi = xx + tap % 3 - 1;
+            if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+            const half_t* xp = x + ((long)((long)n * H + hi) * W + wi) * ldx;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                float v = (float)xp[ci];
+                if (tx) v = umi_tx(v, tx[ci]);
+                const float4* wrow = reinterpret_cast<const float4*>(wsm + (tap * CI + ci) * Co + cg * 8);
+                float4 w0 = wrow[0], w1 = wrow[1];
+                acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]);
+                acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
+                acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]);
+                acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o[j] = (half_t)acc[j];
+            float vr = (float)o[j];
+            s[j] += vr;
+            q[j] = fmaf(vr, vr, q[j]);
+        }
+        *reinterpret_cast<half8*>(y + p * ldy + cg * 8) = o;
+    }
+    if (part) {
+        __syncthreads();
+        float* red = sm;                                   // reuse: [2][256][9]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[(0 * 256 + tid) * 9 + j] = s[j]; red[(1 * 256 + tid) * 9 + j] = q[j]; }
+        __syncthreads();
+        for (int i = tid; i < 2 * Co; i += 256) {
+            int which = i / Co, c = i - which * Co;
+            float a = 0.f;
+            for (int k = 0; k < PL; ++k) a += red[(which * 256 + k * G + (c >> 3)) * 9 + (c & 7)];
+            part[((long)blockIdx.x * 2 + which) * Co + c] = a;
+        }
+    }
+}
+
+// dW[co][ci][tap] partials: grid = (pixel blocks, Ci); thread = (pixel lane, 8 output channels)
+__global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const half_t* __restrict__ x, int ldx,
+                                                            const float4* __restrict__ tx,
+                                                            const half_t* __restrict__ dy, int lddy,
+                                                            float* __restrict__ part, int N, int H, int W, int Ci,
+                                                            int Co) {
+    __shared__ float red[256][9];
+    const int tid = threadIdx.x, ci = blockIdx.y;
+    const int G = Co >> 3, PL = 256 / G;
+    const int cg = tid % G, pl = tid / G;
+    const long P = (long)N * H * W;
+    const long p0 = (long)blockIdx.x * WG_PPB;
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    float4 tc = tx ? tx[ci] : make_float4(0.f, 1.f, 0.f, -INFINITY);
+    for (long p = p0 + pl; p < p0 + WG_PPB && p < P; p += PL) {
+        int n = (int)(p / ((long)H * W));
+        int r = (int)(p - (long)n * H * W);
+        int yy = r / W, xx = r - yy * W;
+        half8 g = *reinterpret_cast<const half8*>(dy + p * lddy + cg * 8);
+        float gf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gf[j] = (float)g[j];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            int hi = yy + tap / 3 - 1, wi = xx + tap % 3 - 1;
+            float v = 0.f;
+            if (hi >= 0 && hi < H && wi >= 0 && wi < W) {
+                v = (float)x[((long)((long)n * H + hi) * W + wi) * ldx + ci];
+                if (tx) v = umi_tx(v, tc);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[tap][j] = fmaf(v, gf[j], acc[tap][j]);
+        }
+    }
+    for (int tap = 0; tap < 9; ++tap) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid][j] = acc[tap][j];
+        __syncthreads();
+        if (tid < Co) {
+            float a = 0.f;
+            for (int k = 0; k < PL; ++k) a += red[k * G + (tid >> 3)][tid & 7];
+            part[(((long)blockIdx.x * 9 + tap) * Ci + ci) * Co + tid] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// head forward: logits[p][k] = bias[k] + sum_c tx(x[p][c]) * w[c][k]   (fp32 out, NHWC, ldy = ncls or more)
+template <int NC>
+__global__ __launch_bounds__(256) void head1x1_fwd_kernel(const half_t* __restrict__ x, int ldx,
+                                                          const float4* __restrict__ tx, const half_t* __restrict__ wp,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int ldy,
+                                                          long P, int C) {
+    const int G = C >> 3;                                   // lanes per pixel (power of two <= 64)
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);
+    const long stride_p = ((long)gridDim.x * 256) / G;
+    float4 t[8];
+    float w[8][NC];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        t[j] = tx ? tx[cg * 8 + j] : make_float4(0.f, 1.f, 0.f, -INFINITY);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) w[j][k] = (float)wp[(cg * 8 + j) * NC + k];
+    }
+    const long Pr = ((P + stride_p - 1) / stride_p) * stride_p;      // keep whole pixel groups in the shuffle
+    for (long p = gt / G; p < Pr; p += stride_p) {
+        float acc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) acc[k] = 0.f;
+        if (p < P) {
+            half8 v = *reinterpret_cast<const half8*>(x + p * ldx + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = umi_tx((float)v[j], t[j]);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) acc[k] = fmaf(a, w[j][k], acc[k]);
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) acc[k] += __shfl_xor(acc[k], o);
+        if (cg == 0 && p < P) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) y[p * ldy + k] = acc[k] + (bias ? bias[k] : 0.f);
+        }
+    }
+}
+
+// head data gradient: da[p][c] = sum_k dl[p][k] * w[k][c]    (K = NC tiny; wp = [NC][C])
+template <int NC>
+__global__ __launch_bounds__(256) void smallk1x1_fwd_kernel(const half_t* __restrict__ x, int ldx,
+                                                            const half_t* __restrict__ wp, half_t* __restrict__ y,
+                                                            int ldy, long P, int C) {
+    const int G = C >> 3;
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);
+    const long stride_p = ((long)gridDim.x * 256) / G;
+    float w[NC][8];
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[k][j] = (float)wp[k * C + cg * 8 + j];
+    for (long p = gt / G; p < P; p += stride_p) {
+        float d[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) d[k] = (float)x[p * ldx + k];
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) a = fmaf(d[k], w[k][j], a);
+            o[j] = (half_t)a;
+        }
+        *reinterpret_cast<half8*>(y + p * ldy + cg * 8) = o;
+    }
+}
+
+// head weight gradient partials: part[blk][0][c][k] = sum_p tx(x[p][c]) * dl[p][k]   (layout [z][tap=0][ci][co])
+template <int NC>
+__global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const half_t* __restrict__ x, int ldx,
+                                                            const float4* __restrict__ tx,
+                                                            const half_t* __restrict__ dl, int lddl,
+                                                            float* __restrict__ part, long P, int C) {
+    __shared__ float red[256][9];
+    const int tid = threadIdx.x;
+    const int G = C >> 3, PL = 256 / G;
+    const int cg = tid % G, pl = tid / G;
+    const long p0 = (long)blockIdx.x * WG_PPB;
+    float4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = tx ? tx[cg * 8 + j] : make_float4(0.f, 1.f, 0.f, -INFINITY);
+    float acc[NC][8];
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    for (long p = p0 + pl; p < p0 + WG_PPB && p < P; p += PL) {
+        half8 v = *reinterpret_cast<const half8*>(x + p * ldx + cg * 8);
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = umi_tx((float)v[j], t[j]);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            float d = (float)dl[p * lddl + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(a[j], d, acc[k][j]);
+        }
+    }
+    for (int k = 0; k < NC; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid][j] = acc[k][j];
+        __syncthreads();
+        if (tid < C) {
+            float s = 0.f;
+            for (int q = 0; q < PL; ++q) s += red[q * G + (tid >> 3)][tid & 7];
+            part[((long)blockIdx.x * C + tid) * NC + k] = s;
+        }
+    }
+}
+
+int grid_for(long items) {
+    long g = (items + 255) / 256;
+    if (g > 8192) g = 8192;
+    return g < 1 ? 1 : (int)g;
+}
+
+bool groups_ok(int C) { return C % 8 == 0 && C / 8 <= 64 && (256 % (C / 8)) == 0; }
+
+}  // namespace
+
+// ---- dispatch helpers used by api.hip -------------------------------------------------------------------------
+bool umi_stem_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldy, int in_dtype, int out_dtype, int flags,
+                     const float* bias) {
+    if (flags & (UMI_CONV_UPSAMPLE2 | UMI_CONV_FORCE_GENERIC)) return false;
+    return in_dtype == UMI_F16 && out_dtype == UMI_F16 && !bias && R == 3 && S == 3 && stride == 1 && pad == 1 &&
+           Ci >= 1 && Ci <= 4 && groups_ok(Co) && ldy % 8 == 0 && 9 * Ci * Co * 4 <= 48 * 1024;
+}
+int umi_stem_stat_rows(int N, int H, int W) { return (int)(((long)N * H * W + STEM_PPB - 1) / STEM_PPB); }
+
+int umi_stem_fwd(const void* x, int ldx, const void* tx, const void* wp, void* y, int ldy, float* part, int N, int H, int W,
+                 int Ci, int Co, hipStream_t s) {
+    if (!al16(y)) return UMI_ERR_BADARG;
+    const int rows = umi_stem_stat_rows(N, H, W);
+    size_t smem = (size_t)9 * Ci * Co * 4;
+    if (smem < 2 * 256 * 9 * 4) smem = 2 * 256 * 9 * 4;
+#define GO(CI) hipLaunchKernelGGL(stem3x3_fwd_kernel<CI>, dim3(rows), dim3(256), smem, s, (const half_t*)x, ldx, (const float4*)tx, (const half_t*)wp, (half_t*)y, ldy, part, N, H, W, Co)
+    switch (Ci) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+bool umi_stem_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int lddy, int dtype, int flags, const void* txb) {
+    if (flags & UMI_CONV_FORCE_GENERIC) return false;
+    return dtype == UMI_F16 && !txb && R == 3 && S == 3 && stride == 1 && pad == 1 && Ci >= 1 && Ci <= 4 && groups_ok(Co) &&
+           Co <= 256 && lddy % 8 == 0;
+}
+size_t umi_stem_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co) {
+    long blocks = ((long)N * H * W + WG_PPB - 1) / WG_PPB;
+    return (size_t)blocks * 9 * Ci * Co * sizeof(float);
+}
+int umi_stem_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
+                   long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (ws_bytes < umi_stem_wgrad_ws_bytes(N, H, W, Ci, Co)) return UMI_ERR_WORKSPACE;
+    if (!al16(dy)) return UMI_ERR_BADARG;
+    int blocks = (int)(((long)N * H * W + WG_PPB - 1) / WG_PPB);
+    hipLaunchKernelGGL(stem3x3_wgrad_kernel, dim3(blocks, Ci), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txa,
+                       (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co);
+    UMI_LAUNCH_CHECK();
+    umi_launch_wgrad_reduce((const float*)ws, blocks, 9, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// head forward: fp16 in, fp32 out, 1x1, Co <= 8 (weights in generic [1][Ci][Co] fp16 packing)
+bool umi_head_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int in_dtype, int out_dtype, int flags) {
+    if (flags & (UMI_CONV_UPSAMPLE2 | UMI_CONV_FORCE_GENERIC)) return false;
+    return in_dtype == UMI_F16 && out_dtype == UMI_F32 && R == 1 && S == 1 && stride == 1 && pad == 0 && Co >= 1 &&
+           Co <= 8 && groups_ok(Ci) && ldx % 8 == 0;
+}
+int umi_head_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy, long P,
+                 int Ci, int Co, hipStream_t s) {
+    if (!al16(x)) return UMI_ERR_BADARG;
+    int grid = grid_for(P * (Ci / 8));
+#define GO(NC) hipLaunchKernelGGL(head1x1_fwd_kernel<NC>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)tx, (const half_t*)wp, bias, (float*)y, ldy, P, Ci)
+    switch (Co) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
+                  case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// tiny-K pointwise conv (the head's data gradient): fp16 -> fp16, Ci <= 8, no transform / bias
+bool umi_smallk_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldy, int in_dtype, int out_dtype, int flags,
+                       const void* tx, const float* bias) {
+    if (flags & (UMI_CONV_UPSAMPLE2 | UMI_CONV_FORCE_GENERIC)) return false;
+    return in_dtype == UMI_F16 && out_dtype == UMI_F16 && !tx && !bias && R == 1 && S == 1 && stride == 1 && pad == 0 &&
+           Ci >= 1 && Ci <= 8 && groups_ok(Co) && ldy % 8 == 0;
+}
+int umi_smallk_fwd(const void* x, int ldx, const void* wp, void* y, int ldy, long P, int Ci, int Co, hipStream_t s) {
+    if (!al16(y)) return UMI_ERR_BADARG;
+    int grid = grid_for(P * (Co / 8));
+#define GO(NC) hipLaunchKernelGGL(smallk1x1_fwd_kernel<NC>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const half_t*)wp, (half_t*)y, ldy, P, Co)
+    switch (Ci) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
+                  case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+bool umi_head_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int dtype, int flags, const void* txb) {
+    if (flags & UMI_CONV_FORCE_GENERIC) return false;
+    return dtype == UMI_F16 && !txb && R == 1 && S == 1 && stride == 1 && pad == 0 && Co >= 1 && Co <= 8 && groups_ok(Ci) &&
+           Ci <= 256 && ldx % 8 == 0;
+}
+size_t umi_head_wgrad_ws_bytes(long P, int Ci, int Co) {
+    return (size_t)((P + WG_PPB - 1) / WG_PPB) * Ci * Co * sizeof(float);
+}
+int umi_head_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
+                   long s_t, float out_scale, long P, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (ws_bytes < umi_head_wgrad_ws_bytes(P, Ci, Co)) return UMI_ERR_WORKSPACE;
+    if (!al16(x)) return UMI_ERR_BADARG;
+    int blocks = (int)((P + WG_PPB - 1) / WG_PPB);
+#define GO(NC) hipLaunchKernelGGL(head1x1_wgrad_kernel<NC>, dim3(blocks), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, P, Ci)
+    switch (Co) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
+                  case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    umi_launch_wgrad_reduce((const float*)ws, blocks, 1, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
