@@ -225,3 +225,26 @@ def test_stem_and_head_fast_paths(cin):
     act = _apply_tx(a.float().cpu(), t.cpu())
     ref = F.conv2d(act.permute(0, 3, 1, 2), wo.half().float().cpu(), b.cpu()).permute(0, 2, 3, 1)
     assert (res["fast"][0] - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 6, 128, 64), (1, 16, 16, 64, 128), (2, 9, 37, 256, 128)])
+def test_conv_transpose_wgrad_mfma(shape):
+    """dW of ConvTranspose2d(k2,s2): hi-res gradient x low-res (BN+ReLU-on-load) input, MFMA vs generic vs autograd."""
+    lib, ops = _gpu()
+    N, h, w, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    xin = torch.randn(N, h, w, Cin, generator=g).half()
+    t = _tx(Cin, g)
+    dup = (torch.randn(N, 2 * h, 2 * w, Cout, generator=g) * 0.1).half()
+    a = _apply_tx(xin.float(), t).permute(0, 3, 1, 2)
+    wr = torch.zeros(Cin, Cout, 2, 2, requires_grad=True)
+    F.conv_transpose2d(a, wr, None, stride=2).backward(dup.float().permute(0, 3, 1, 2))
+    ref = wr.grad
+    res = {}
+    for name, flags in (("mfma", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        gw = torch.empty(Cin, Cout, 2, 2, device=DEV)
+        ops.conv_wgrad(dup.to(DEV), None, xin.to(DEV), t.to(DEV), gw, Cout * 4, 4, 1, 1.0, 2, 2, 2, 0, flags=flags)
+        res[name] = gw.cpu()
+    scale = ref.abs().max().item()
+    assert (res["generic"] - ref).abs().max().item() < 2e-3 * scale
+    assert (res["mfma"] - ref).abs().max().item() < 6e-3 * scale

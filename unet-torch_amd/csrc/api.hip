@@ -44,6 +44,12 @@ bool umi_head_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int ld
 size_t umi_head_wgrad_ws_bytes(long P, int Ci, int Co);
 int umi_head_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
                    long s_t, float out_scale, long P, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s);
+bool umi_wgradT_mfma_ok(int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int ldx,
+                        int lddy, int dtype, int flags, const void* txa);
+size_t umi_wgradT_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co);
+int umi_wgradT_mfma(const void* x, int ldx, const void* dy, int lddy, const void* txb, float* dW, long s_co, long s_ci,
+                    long s_t, float out_scale, int N, int Ho, int Wo, int Ci, int Co, void* ws, size_t ws_bytes,
+                    hipStream_t s);
 bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
                           int ldx, int lddy, int dtype, int flags, const void* txb);
 size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co);
@@ -115,6 +121,10 @@ extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co,
         size_t m = umi_wgrad3x3_mfma_ws_bytes(N, Ho, Wo, Ci, Co);
         if (m > g) g = m;
     }
+    if (umi_wgradT_mfma_ok(2 * Ho, 2 * Wo, Ci, Co, R, S, 2, 0, Ho, Wo, 8, 8, dtype, flags, nullptr)) {
+        size_t m = umi_wgradT_mfma_ws_bytes(N, Ho, Wo, Ci, Co);
+        if (m > g) g = m;
+    }
     if (umi_stem_wgrad_ok(Ci, Co, R, S, 1, 1, 8, dtype, flags, nullptr)) {
         size_t m = umi_stem_wgrad_ws_bytes(N, Ho, Wo, Ci, Co);
         if (m > g) g = m;
@@ -135,6 +145,9 @@ extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const voi
     if (umi_wgrad3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, lddy, dtype, flags, txb))
         return umi_wgrad3x3_mfma(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes,
                                  (hipStream_t)stream);
+    if (umi_wgradT_mfma_ok(H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, lddy, dtype, flags, txa))
+        return umi_wgradT_mfma(x, ldx, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, Ho, Wo, Ci, Co, ws, ws_bytes,
+                               (hipStream_t)stream);
     if (umi_stem_wgrad_ok(Ci, Co, R, S, stride, pad, lddy, dtype, flags, txb))
         return umi_stem_wgrad(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes,
                               (hipStream_t)stream);

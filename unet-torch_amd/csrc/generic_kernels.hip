@@ -660,26 +660,41 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int RS, int Ci, int Co,
-                                    float* __restrict__ dW, long s_co, long s_ci, long s_t, float scale) {
-    long total = (long)RS * Ci * Co;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int co = (int)(i % Co);
-        long rr = i / Co;
-        int ci = (int)(rr % Ci);
-        int t = (int)(rr / Ci);
+// Fixed-order split-K reduction: block = 32 outputs x 8 split lanes; lane l sums splits l, l+8, ... then the 8 lane
+// sums are added in lane order (deterministic for a given number of splits).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int RS, int Ci,
+                                                           int Co, float* __restrict__ dW, long s_co, long s_ci, long s_t,
+                                                           float scale) {
+    __shared__ float red[8][33];
+    const long total = (long)RS * Ci * Co;
+    const int ox = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (long base = (long)blockIdx.x * 32; base < total; base += (long)gridDim.x * 32) {
+        long i = base + ox;
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += part[(long)z * total + i];
-        dW[co * s_co + ci * s_ci + t * s_t] = s * scale;
+        if (i < total)
+            for (int z = sl; z < splits; z += 8) s += part[(long)z * total + i];
+        red[sl][ox] = s;
+        __syncthreads();
+        if (sl == 0 && i < total) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += red[k][ox];
+            int co = (int)(i % Co);
+            long rr = i / Co;
+            int ci = (int)(rr % Ci);
+            int t = (int)(rr / Ci);
+            dW[co * s_co + ci * s_ci + t * s_t] = a * scale;
+        }
+        __syncthreads();
     }
 }
 
 void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
                              long s_t, float scale, hipStream_t st) {
     long total = (long)RS * Ci * Co;
-    int g = (int)((total + 255) / 256);
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
+    long g = (total + 31) / 32;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
 }
 
 static void wgrad_generic_plan(long P, int Ci, int Co, int RS, int* splits, long* chunk) {
@@ -714,10 +729,7 @@ int umi_conv_wgrad_generic(const void* x, int ldx, const void* txa, const void* 
     else if (dtype == UMI_F16) hipLaunchKernelGGL(wgrad_generic_kernel<half_t>, grid, block, 0, st, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (const float4*)txb, (float*)ws, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, chunk, tiles_co);
     else return UMI_ERR_BADARG;
     UMI_LAUNCH_CHECK();
-    long total = (long)R * S * Ci * Co;
-    int g = (int)((total + 255) / 256);
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, (const float*)ws, splits, R * S, Ci, Co, dW, s_co, s_ci, s_t, out_scale);
+    umi_launch_wgrad_reduce((const float*)ws, splits, R * S, Ci, Co, dW, s_co, s_ci, s_t, out_scale, st);
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }

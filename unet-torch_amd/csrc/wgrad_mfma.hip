@@ -172,6 +172,146 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 2x2 stride-2 pair (ConvTranspose2d(k=2,s=2) and its adjoint), reference Model.py:56-57:
+//   dW[tap][cx][cy] = sum over low-res pixels p   X[2p + tap][cx] * tx(Y[p])[cy]
+// X = hi-res tensor (2h x 2w, e.g. the gradient of the upsampled map), Y = low-res tensor (the ConvT input, BN+ReLU
+// applied on load).  Same transposing-read scheme; the stride-2 pixel walk of X is free because every lane supplies
+// its own row address to ds_read_b64_tr_b16.  Tile = 2 low-res rows x 32 pixels; 4 accumulator tiles per wave.
+constexpr int T2R = 2;                                   // low-res rows per tile
+constexpr int X2_PIX = 2 * T2R * 64;                     // hi-res pixels per tile (4 rows x 64)
+constexpr int X2_CHUNK = X2_PIX * PROW;                  // 16384
+constexpr int Y2_CHUNK = T2R * 32 * PROW;                // 4096
+constexpr int SMEM2 = 2 * X2_CHUNK + 2 * Y2_CHUNK;       // 40960
+constexpr int KPX2 = X2_PIX * 8 / 256;                   // 8
+constexpr int KPY2 = T2R * 32 * 8 / 256;                 // 2
+
+__device__ __forceinline__ half8 tr_frag_s2(const unsigned char* p) {      // pixel stride 2 along K
+    typedef __attribute__((address_space(3))) short4v* lds_ptr;
+    short4v r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    short4v r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 8 * PROW));
+    half4 h0 = __builtin_bit_cast(half4, r0), h1 = __builtin_bit_cast(half4, r1);
+    return __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool HAS_TX>
+__global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
+    const half_t* __restrict__ x, int ldx, const half_t* __restrict__ y, int ldy, const float4* __restrict__ txy,
+    float* __restrict__ part, int N, int h, int w, int Cx, int Cy, int tiles_x, int tiles_y, int tiles_total,
+    int tiles_per_split, int n_cy_t) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wcx = wave >> 1, wcy = wave & 1;
+    const int cx0 = (blockIdx.x / n_cy_t) * 64, cy0 = (blockIdx.x % n_cy_t) * 64;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    int t_end = t_begin + tiles_per_split;
+    if (t_end > tiles_total) t_end = tiles_total;
+    const int H2 = 2 * h, W2 = 2 * w;
+
+    const int sub = tid & 7;
+    const int x_lds = (sub >> 2) * X2_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;                  // + k*32*PROW
+    const int y_lds = 2 * X2_CHUNK + (sub >> 2) * Y2_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;   // + k*32*PROW
+    const half_t* xin = x + cx0 + sub * 8;
+    const half_t* yin = y + cy0 + sub * 8;
+
+    floatx16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    half8 xraw[KPX2], yraw[KPY2];
+    bool yvalid[KPY2];
+    half8 zero8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
+
+#define UMI_ISSUE2(tile_)                                                                                        \
+    do {                                                                                                        \
+        const int tt = (tile_);                                                                                 \
+        const int n_ = tt / (tiles_x * tiles_y);                                                                \
+        const int rm_ = tt - n_ * tiles_x * tiles_y;                                                            \
+        const int ty0_ = (rm_ / tiles_x) * T2R, tx0_ = (rm_ % tiles_x) * 32;                                    \
+        _Pragma("unroll") for (int k = 0; k < KPX2; ++k) {                                                      \
+            int gy = 2 * ty0_ + (k >> 1), gx = 2 * tx0_ + (tid >> 3) + 32 * (k & 1);                            \
+            xraw[k] = (gy < H2 && gx < W2)                                                                      \
+                          ? *reinterpret_cast<const half8*>(xin + ((long)((long)n_ * H2 + gy) * W2 + gx) * ldx) \
+                          : zero8;                                                                              \
+        }                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < KPY2; ++k) {                                                      \
+            int gy = ty0_ + k, gx = tx0_ + (tid >> 3);                                                          \
+            yvalid[k] = gy < h && gx < w;                                                                       \
+            yraw[k] = yvalid[k] ? *reinterpret_cast<const half8*>(yin + ((long)((long)n_ * h + gy) * w + gx) * ldy) \
+                                : zero8;                                                                        \
+        }                                                                                                       \
+    } while (0)
+
+    const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+    const int ch_lane = (16 * (g & 1) + 4 * lp) * 2;
+    const unsigned char* x_frag = smem + wcx * X2_CHUNK + 2 * (8 * (g >> 1) + lq) * PROW + ch_lane;
+    const unsigned char* y_frag = smem + 2 * X2_CHUNK + wcy * Y2_CHUNK + (8 * (g >> 1) + lq) * PROW + ch_lane;
+
+    if (t_begin < t_end) UMI_ISSUE2(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        if (HAS_TX) {
+            int opaque = 0;
+            asm volatile("" : "+v"(opaque));
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = txy[cy0 + sub * 8 + j + opaque];
+#pragma unroll
+            for (int k = 0; k < KPY2; ++k)
+                if (yvalid[k]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) yraw[k][j] = (half_t)umi_tx((float)yraw[k][j], t[j]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < KPX2; ++k) *reinterpret_cast<half8*>(smem + x_lds + k * 32 * PROW) = xraw[k];
+#pragma unroll
+        for (int k = 0; k < KPY2; ++k) *reinterpret_cast<half8*>(smem + y_lds + k * 32 * PROW) = yraw[k];
+        __syncthreads();
+        if (tile + 1 < t_end) UMI_ISSUE2(tile + 1);
+#pragma unroll
+        for (int r = 0; r < T2R; ++r)
+#pragma unroll
+            for (int xh = 0; xh < 2; ++xh) {
+                half8 bfr = tr_frag(y_frag + (r * 32 + 16 * xh) * PROW);
+#pragma unroll
+                for (int tap = 0; tap < 4; ++tap) {
+                    half8 afr = tr_frag_s2(x_frag + ((2 * r + (tap >> 1)) * 64 + 32 * xh + (tap & 1)) * PROW);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr, acc[tap], 0, 0, 0);
+                }
+            }
+        __syncthreads();
+    }
+#undef UMI_ISSUE2
+    const int cy = cy0 + wcy * 32 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int cx = cx0 + wcx * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            part[(((long)blockIdx.y * 4 + tap) * Cx + cx) * Cy + cy] = acc[tap][r];
+        }
+}
+
+void planT(int N, int h, int w, int Cx, int Cy, int* tiles_x, int* tiles_y, int* tiles_total, int* splits, int* tps) {
+    *tiles_x = (w + 31) / 32;
+    *tiles_y = (h + T2R - 1) / T2R;
+    *tiles_total = N * (*tiles_x) * (*tiles_y);
+    const long pairs = (long)(Cx / 64) * (Cy / 64);
+    long want = (1024 + pairs - 1) / pairs;
+    const long slab = 4L * Cx * Cy * 4;
+    long cap = (64L << 20) / slab;
+    if (cap < 1) cap = 1;
+    if (pairs * cap < 512 && pairs < 512) cap = (512 + pairs - 1) / pairs;
+    if (want > cap) want = cap;
+    if (want > *tiles_total) want = *tiles_total;
+    if (want < 1) want = 1;
+    *tps = (int)((*tiles_total + want - 1) / want);
+    *splits = (*tiles_total + *tps - 1) / *tps;
+}
+
 void plan(int N, int H, int W, int Ci, int Co, int* tiles_x, int* tiles_y, int* tiles_total, int* splits, int* tps) {
     *tiles_x = (W + 31) / 32;
     *tiles_y = (H + TR - 1) / TR;
@@ -190,6 +330,42 @@ void plan(int N, int H, int W, int Ci, int Co, int* tiles_x, int* tiles_y, int* 
 }
 
 }  // namespace
+
+bool umi_wgradT_mfma_ok(int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int ldx,
+                        int lddy, int dtype, int flags, const void* txa) {
+    if (flags & UMI_CONV_FORCE_GENERIC) return false;
+    if (dtype != UMI_F16 || txa) return false;
+    if (R != 2 || S != 2 || stride != 2 || pad != 0 || H != 2 * Ho || W != 2 * Wo) return false;
+    if (Ci % 64 || Co % 64 || ldx % 8 || lddy % 8) return false;
+    return true;
+}
+
+size_t umi_wgradT_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co) {
+    int tx_, ty_, tt, splits, tps;
+    planT(N, Ho, Wo, Ci, Co, &tx_, &ty_, &tt, &splits, &tps);
+    return (size_t)splits * 4 * Ci * Co * sizeof(float);
+}
+
+int umi_wgradT_mfma(const void* x, int ldx, const void* dy, int lddy, const void* txb, float* dW, long s_co, long s_ci,
+                    long s_t, float out_scale, int N, int Ho, int Wo, int Ci, int Co, void* ws, size_t ws_bytes,
+                    hipStream_t s) {
+    int tiles_x, tiles_y, tiles_total, splits, tps;
+    planT(N, Ho, Wo, Ci, Co, &tiles_x, &tiles_y, &tiles_total, &splits, &tps);
+    if (ws_bytes < (size_t)splits * 4 * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
+    if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
+    const int n_cy_t = Co / 64;
+    dim3 grid((Ci / 64) * n_cy_t, splits), block(256);
+    if (txb)
+        hipLaunchKernelGGL(wgradT2x2_mfma_kernel<true>, grid, block, 0, s, (const half_t*)x, ldx, (const half_t*)dy, lddy,
+                           (const float4*)txb, (float*)ws, N, Ho, Wo, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_cy_t);
+    else
+        hipLaunchKernelGGL(wgradT2x2_mfma_kernel<false>, grid, block, 0, s, (const half_t*)x, ldx, (const half_t*)dy, lddy,
+                           (const float4*)txb, (float*)ws, N, Ho, Wo, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_cy_t);
+    UMI_LAUNCH_CHECK();
+    umi_launch_wgrad_reduce((const float*)ws, splits, 4, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
 
 bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
                           int ldx, int lddy, int dtype, int flags, const void* txb) {
