@@ -14,8 +14,9 @@
  *  - Activations are NHWC with an explicit pixel stride `ld` (elements), so a tensor may
  *    be a channel slice of a wider concat buffer.  dtype: UMI_F32 / UMI_F16 storage,
  *    accumulation is always fp32.
- *  - Input transform `tx` (nullable): one float4 per input channel {sub, scale, shift, lo};
- *    a conv/pool/etc. consumes  max((x - sub) * scale + shift, lo)  of the stored value,
+ *  - Input transform `tx` (nullable): one float4 per input channel {mean, scale, shift, lo};
+ *    a conv/pool/etc. consumes  max(fma(x, scale, shift), lo)  of the stored value (`mean` is only
+ *    read by the BatchNorm backward kernels),
  *    i.e. BatchNorm-apply + ReLU of the producer is fused into the consumer's load
  *    (lo = 0 for ReLU channels, -inf for pass-through channels of a concat buffer).
  *    Zero padding is applied AFTER the transform, as in the reference
@@ -76,7 +77,7 @@ int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int S, int str
 
 /* BatchNorm2d training statistics -> consumer transform (reference Model.py:17,21 =
  * nn.BatchNorm2d: biased batch variance for normalisation, unbiased into running_var,
- * momentum 0.1).  tx_out[c] = {mean, gamma*rstd, beta, 0}; running stats updated in place
+ * momentum 0.1).  tx_out[c] = {mean, gamma*rstd, beta - mean*gamma*rstd, 0}; running stats updated in place
  * when non-null. */
 int umi_bn_finalize(const float* stat_part, int rows, int C, double count,
                     const float* gamma, const float* beta, float eps, float momentum,

@@ -25,7 +25,7 @@ def _tx(C, gen, relu=True):
 
 
 def _apply_tx(x_nhwc, t):
-    return torch.maximum((x_nhwc - t[:, 0]) * t[:, 1] + t[:, 2], t[:, 3])
+    return torch.maximum(x_nhwc * t[:, 1] + t[:, 2], t[:, 3])      # t[:, 0] (mean) is only used by BN backward
 
 
 def _ref_conv(x_nhwc, t, w, stride=1, pad=1):

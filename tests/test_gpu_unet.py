@@ -264,3 +264,24 @@ def test_forward_is_deterministic():
         outs.append((y.detach().clone(), [p.grad.clone() for p in m.parameters()]))
     assert torch.equal(outs[0][0], outs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+def test_grad_reducer_sink_path_matches_plain_backward():
+    """Data-parallel sink (flat buckets written directly by the wgrad kernels, umi/ddp.py) with world size 1:
+    gradients must equal the plain tape's bit for bit, and land in the reducer's buckets."""
+    _need_gpu()
+    import Model
+    from umi import ddp
+    torch.manual_seed(3)
+    m = Model.UNet(1, 2, 8, compute_dtype="fp16").to(DEV).train()
+    x = torch.randn(2, 1, 32, 32, device=DEV)
+    m(x).square().mean().backward()
+    plain = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    red = ddp.GradReducer(m, world_size=1, bucket_mb=0.5)
+    assert len(red.buckets) > 1
+    m(x).square().mean().backward()
+    red.sync()
+    for p, g in zip(m.parameters(), plain):
+        assert torch.equal(p.grad, g)
+        assert torch.equal(red.buffer_for(p), g)

@@ -13,11 +13,12 @@ typedef _Float16 half_t;
         if (e__ != hipSuccess) return (int)e__;               \
     } while (0)
 
-// Consumer-side transform of a stored activation: max((x - sub) * scale + shift, lo).
-// t = {sub, scale, shift, lo}.  `pre` is the value before the clamp (needed by the
-// ReLU mask in backward kernels).
+// Consumer-side transform of a stored activation: max(fma(x, scale, shift), lo) -- ONE fp32 fma + max per
+// element, evaluated identically by every kernel that needs the activation or its ReLU mask.
+// t = {mean, scale, shift, lo}: for BatchNorm scale = gamma*rstd, shift = beta - mean*scale; `mean` is only
+// read by the BatchNorm backward kernels (xhat).  `pre` is the value before the clamp (the ReLU mask).
 __device__ __forceinline__ float umi_tx_pre(float v, const float4 t) {
-    return fmaf(v - t.x, t.y, t.z);
+    return fmaf(v, t.y, t.z);
 }
 __device__ __forceinline__ float umi_tx(float v, const float4 t) {
     return fmaxf(umi_tx_pre(v, t), t.w);

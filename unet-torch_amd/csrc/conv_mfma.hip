@@ -74,24 +74,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const int q = tid & 1;                         // which 8-channel half of the 16-channel chunk this thread stages
 
     // ---- per-thread staging plan (fixed across chunks) ------------------------------------------
+    // Loads go through buffer descriptors: an out-of-range voffset returns zeros, so zero padding and partial
+    // tiles need no branches around the loads.  The per-chunk offset rides in the scalar soffset.
     // halo piece k of this thread: index i = tid + 256k -> halo pixel hp = (tid>>1) + 128k, channel half q
-    int pix[C::KPH];                               // linear pixel index inside image n, or -1 (zero padding / no piece)
+    constexpr unsigned OOB = 0x7FFFFFFFu;
+    unsigned hoff[C::KPH];                         // byte offset inside image n, or OOB (zero padding / no piece)
 #pragma unroll
     for (int k = 0; k < C::KPH; ++k) {
         int hp = (tid >> 1) + 128 * k;
         int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         bool inimg = (hp < C::HALO_PIX) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        pix[k] = inimg ? gy * W + gx : -1;
+        hoff[k] = inimg ? (unsigned)(gy * W + gx) * (unsigned)(ldx * 2) + q * 16 : OOB;
     }
-    const half_t* xin = x + (long)n * H * W * ldx + q * 8;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(x + (long)n * H * W * ldx), 0, (int)((long)H * W * ldx * 2), 0x00020000);
     const int hl_base = (tid >> 1) * ROWB + q * 16;           // + k * 128 * ROWB
     // weight piece k: row rc = (tid>>1) + 128k of the [9*BN] rows -> tap = k*(128/BN) + (tid>>1)/BN
     constexpr int TSTEP = 128 / BN;
     const int tap0 = (tid >> 1) / BN, wcol = (tid >> 1) % BN;
     const int Ci8 = Ci >> 3;
-    const half_t* win = wp8 + ((long)((long)tap0 * Ci8 + q) * Co + c0 + wcol) * 8;
-    const long wstep = (long)TSTEP * Ci8 * Co * 8;              // elements per k step
+    const unsigned wbase = (unsigned)(((tap0 * Ci8 + q) * Co + wcol) * 16);
+    const unsigned wstep = (unsigned)(TSTEP * Ci8 * Co * 16);   // bytes per k step
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(wp8 + (long)c0 * 8), 0, (int)((long)9 * Ci * Co * 2 - (long)c0 * 16), 0x00020000);
     const int wl_base = C::HB + (tid >> 1) * ROWB + q * 16;    // + k * 128 * ROWB
 
     floatx16 acc[2][4];
@@ -103,16 +109,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     half8 hraw[C::KPH], wraw[C::KPW];
-    half8 zero8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
 #define UMI_ISSUE(c_)                                                                                              \
     do {                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < C::KPH; ++k)                                                        \
-            hraw[k] = pix[k] >= 0 ? *reinterpret_cast<const half8*>(xin + (long)pix[k] * ldx + (c_) * 16) : zero8; \
+            hraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[k], (c_) * 32, 0)); \
         _Pragma("unroll") for (int k = 0; k < C::KPW; ++k)                                                        \
-            wraw[k] = (tap0 + k * TSTEP < 9)                                                                      \
-                          ? *reinterpret_cast<const half8*>(win + k * wstep + (long)(c_) * 2 * Co * 8) : zero8;   \
+            wraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                            \
+                wrs, (tap0 + k * TSTEP < 9) ? wbase + k * wstep : OOB, (c_) * 2 * Co * 16, 0));                   \
     } while (0)
 
     // fragment base addresses (bytes)
@@ -121,8 +124,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const int a_base = C::HB + (wn * 64 + lrow) * ROWB + lhalf * 16;                 // + (tap*BN + mt*32)*48
 
     const int nchunks = Ci >> 4;
-    UMI_ISSUE(0);
-    for (int c = 0; c < nchunks; ++c) {
+    // (Rotating the chunk order per workgroup to spread the weight reads over L2 channels was measured and is
+    //  SLOWER: -12 % on 1024->1024; simultaneous readers of one panel share L2 lines.)
+#define UMI_CHUNK(i_) (i_)
+    UMI_ISSUE(UMI_CHUNK(0));
+    for (int ci_ = 0; ci_ < nchunks; ++ci_) {
+        const int c = UMI_CHUNK(ci_);
         // ---- registers -> (transform) -> LDS ----------------------------------------------------
         if (HAS_TX) {
             float4 t[8];
@@ -130,22 +137,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             for (int j = 0; j < 8; ++j) t[j] = tx[c * 16 + q * 8 + j];
 #pragma unroll
             for (int k = 0; k < C::KPH; ++k) {
-                if (pix[k] >= 0) {
+                if (hoff[k] != OOB) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) hraw[k][j] = (half_t)umi_tx((float)hraw[k][j], t[j]);
                 }
             }
         }
+#ifndef UMI_EXP_NO_STAGE
 #pragma unroll
         for (int k = 0; k < C::KPH; ++k)
             if ((tid >> 1) + 128 * k < C::HALO_PIX) *reinterpret_cast<half8*>(smem + hl_base + k * 128 * ROWB) = hraw[k];
 #pragma unroll
         for (int k = 0; k < C::KPW; ++k)
             if (tap0 + k * TSTEP < 9) *reinterpret_cast<half8*>(smem + wl_base + k * 128 * ROWB) = wraw[k];
+#else
+#pragma unroll
+        for (int k = 0; k < C::KPH; ++k) asm volatile("" ::"v"(hraw[k]));
+#pragma unroll
+        for (int k = 0; k < C::KPW; ++k) asm volatile("" ::"v"(wraw[k]));
+#endif
         __syncthreads();
-        if (c + 1 < nchunks) UMI_ISSUE(c + 1);
+        if (ci_ + 1 < nchunks) UMI_ISSUE(UMI_CHUNK(ci_ + 1));
 
         // ---- MFMA phase: 9 taps x (2 x 4) tiles -----------------------------------------------
+#ifndef UMI_EXP_NO_MFMA
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             half8 bf[6];
@@ -165,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt + dy], acc[mt][nt], 0, 0, 0);
             }
         }
+#endif
         __syncthreads();
     }
 
@@ -240,6 +256,7 @@ int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int
 }
 
 #undef UMI_ISSUE
+#undef UMI_CHUNK
 }  // namespace
 
 // Shapes the MFMA path takes; everything else goes to the generic kernel.
@@ -253,7 +270,12 @@ bool umi_conv3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int 
     return true;
 }
 
-static int pick_th(int Co) { return (Co % 128 == 0) ? 8 : 16; }
+#ifdef UMI_FORCE_BN64
+static bool use_bn128(int Co) { (void)Co; return false; }
+#else
+static bool use_bn128(int Co) { return Co % 128 == 0; }
+#endif
+static int pick_th(int Co) { return use_bn128(Co) ? 8 : 16; }
 
 int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Co) {
     const int th = pick_th(Co);
@@ -262,6 +284,6 @@ int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Co) {
 
 int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
                      int N, int H, int W, int Ci, int Co, hipStream_t s) {
-    if (Co % 128 == 0) return launch<8, 128>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, s);
+    if (use_bn128(Co)) return launch<8, 128>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, s);
     return launch<16, 64>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, s);
 }

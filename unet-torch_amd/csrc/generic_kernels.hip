@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         if (var < 0.0) var = 0.0;
         double rstd = 1.0 / sqrt(var + (double)eps);
         float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-        tx_out[c] = make_float4((float)mean, (float)((double)g * rstd), b, 0.f);
+        const double scale = (double)g * rstd;
+        tx_out[c] = make_float4((float)mean, (float)scale, (float)((double)b - mean * scale), 0.f);
         if (rstd_out) rstd_out[c] = (float)rstd;
         if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
         if (rvar) {

@@ -64,7 +64,8 @@ def passthrough_tx(C, device):
 def eval_bn_tx(weight, bias, running_mean, running_var, eps):
     """Consumer transform for BatchNorm in eval mode (running statistics) + ReLU."""
     rstd = torch.rsqrt(running_var.float() + eps)
-    return torch.stack([running_mean.float(), weight.float() * rstd, bias.float(),
+    scale = weight.float() * rstd
+    return torch.stack([running_mean.float(), scale, bias.float() - running_mean.float() * scale,
                         torch.zeros_like(rstd)], dim=1).contiguous(), rstd
 
 
