@@ -1,0 +1,70 @@
+"""TransUNet fixtures from the REFERENCE itself (called by tools/gen_golden.py; build container only).
+
+Builds reference `TransUnet.vit_seg_modeling.VisionTransformer` from a ConfigDict equivalent to the oracle's plain
+dict config, loads the build-owned recipe weights, runs forward + `dice_bce_mc` + backward (+1 SGD step), and stores
+numeric outputs only.  Dropout is set to 0.0 in the config (CPU/GPU RNG streams cannot match).
+"""
+import os
+
+import numpy as np
+import torch
+
+from oracle import recipe, ref_transunet
+
+
+def _ref_config(cfg, img_size):
+    import ml_collections
+    C = ml_collections.ConfigDict
+    g = img_size // 16
+    c = C(dict(patches=C({"size": (16, 16), "grid": (g, g)}), hidden_size=cfg["hidden_size"],
+               transformer=C(dict(mlp_dim=cfg["mlp_dim"], num_heads=cfg["num_heads"], num_layers=cfg["num_layers"],
+                                  attention_dropout_rate=cfg["attention_dropout_rate"], dropout_rate=cfg["dropout_rate"])),
+               classifier="seg", representation_size=None, resnet_pretrained_path=None, pretrained_path=None, patch_size=16,
+               decoder_channels=tuple(cfg["decoder_channels"]), n_classes=cfg["n_classes"], activation="softmax",
+               resnet=C(dict(num_layers=tuple(cfg["resnet_layers"]), width_factor=cfg["width_factor"])),
+               skip_channels=list(cfg["skip_channels"]), n_skip=cfg["n_skip"]))
+    return c
+
+
+def _case(vsm, loss_mod, sig, meta, GOLD, name, cfg, img, B, cin, seed, full):
+    torch.manual_seed(0)
+    loss_mod.CLASS_NUMBER = cfg["n_classes"]
+    m = vsm.VisionTransformer(_ref_config(cfg, img), img_size=img, num_classes=cfg["n_classes"])
+    out = dict(img=img, B=B, cin=cin, seed=seed, n_keys=len(m.state_dict()))
+    out["keys"] = np.array(list(m.state_dict().keys()))
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed, negative_gamma=False))
+    x, lab = recipe.synthetic_batch(B, cin, img, img, cfg["n_classes"], seed=seed)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    m.train()
+    logits = m(x)
+    loss = loss_mod.calc_loss(logits, lab, loss_type="dice_bce_mc")
+    opt.zero_grad()
+    loss.backward()
+    out["logits_sig"] = sig(logits)
+    out["loss0"] = loss.item()
+    if full:
+        out["logits"] = logits.detach().numpy()
+    for k, p in m.named_parameters():
+        out["grad_sig." + k] = sig(p.grad)
+    opt.step()
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k or full:
+            out["after1." + k] = sig(v.float())
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)
+    out["eval_logits_sig"] = sig(ev)
+    if full:
+        out["eval_logits"] = ev.numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out, **meta())
+    print(f"wrote {name}.npz keys={out['n_keys']} loss0={out['loss0']:.6f}")
+
+
+def run(import_reference, sig, meta, GOLD, big=False):
+    _, loss_mod, _ = import_reference()
+    from TransUnet import vit_seg_modeling as vsm
+    _case(vsm, loss_mod, sig, meta, GOLD, "transunet_small", ref_transunet.small_config(2), 64, 2, 1, 31, True)
+    _case(vsm, loss_mod, sig, meta, GOLD, "transunet_small_rgb4", ref_transunet.small_config(4), 96, 1, 3, 32, True)
+    if big:
+        cfg = ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)
+        _case(vsm, loss_mod, sig, meta, GOLD, "transunet_r50_b16_224", cfg, 224, 1, 1, 33, False)
