@@ -38,7 +38,9 @@ enum { UMI_F32 = 0, UMI_F16 = 1 };
 enum { UMI_OK = 0, UMI_ERR_BADARG = -1, UMI_ERR_UNSUPPORTED = -2, UMI_ERR_WORKSPACE = -3 };
 /* umi_conv_fwd flags */
 enum { UMI_CONV_UPSAMPLE2 = 1,   /* ConvTranspose2d(k=2,s=2): tap t=(dy,dx) scatters to (2h+dy+off_h, 2w+dx+off_w) */
-       UMI_CONV_FORCE_GENERIC = 2 /* never take the MFMA fast path (used by tests to cross-check it) */ };
+       UMI_CONV_FORCE_GENERIC = 2, /* never take the MFMA fast path (used by tests to cross-check it) */
+       UMI_CONV_DGRAD_STRIDED = 4  /* data gradient of a stride>1 conv: x = dy [N,H,W,Ci:=Co_fwd], y = dx [N,Ho,Wo,Co:=Ci_fwd]
+                                      with (R,S,stride,pad) of the FORWARD conv; weights packed [R*S][Co_fwd][Ci_fwd] unflipped */ };
 
 int umi_version(void);
 const char* umi_arch(void);          /* "gfx950" */
@@ -124,6 +126,59 @@ int umi_colsum(const void* x, int ldx, float* out, float out_scale, long M, int 
  * reference block returns (e.g. DoubleConv.forward, reference Model.py:25-26). */
 int umi_materialize_nchw(const void* x, int ldx, const void* tx, float* y_nchw,
                          int N, int H, int W, int C, int dtype, umi_stream_t stream);
+
+/* ---- TransUNet path (reference TransUnet/vit_seg_modeling.py, vit_seg_modeling_resnet_skip.py) -------------------- */
+
+/* StdConv2d weight standardisation and its backward (resnet_skip.py:20-23): per output channel over K = Ci*R*S,
+ * biased variance, w_std = (w - mean) / sqrt(var + eps). fp32 parameters. */
+int umi_wstd_fwd(const float* w, float* wstd, float* rstd, int Co, int K, float eps, umi_stream_t stream);
+int umi_wstd_bwd(const float* wstd, const float* rstd, const float* g, float* dw, int Co, int K, umi_stream_t stream);
+
+/* GroupNorm (+ optional residual add, + optional ReLU) on NHWC, y = [relu](gn(x) [+ res]) (resnet_skip.py:47-58,68-73).
+ * mean/rstd: [N*G] saved for backward.  Backward: dx (and dres = masked dy when dres != NULL), dgamma/dbeta scaled by
+ * out_scale; `y` is the forward OUTPUT (ReLU mask). */
+int umi_gn_fwd(const void* x, int ldx, const float* gamma, const float* beta, const void* res, int ldr, void* y, int ldy,
+               float* mean, float* rstd, int relu, int N, long HW, int C, int G, float eps, int dtype, umi_stream_t stream);
+size_t umi_gn_bwd_ws_bytes(int N, int C, int G);
+int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
+               const float* rstd, const float* gamma, int relu, void* dx, int lddx, void* dres, int lddr,
+               float* dgamma, float* dbeta, float out_scale, int N, long HW, int C, int G, int dtype,
+               void* ws, size_t ws_bytes, umi_stream_t stream);
+
+/* MaxPool2d(kernel 3, stride 2, pad 0) (resnet_skip.py:147) and its backward (first-max tie rule). */
+int umi_pool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, umi_stream_t stream);
+int umi_pool3s2_bwd(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx, int N, int H, int W, int C,
+                    int dtype, umi_stream_t stream);
+
+/* LayerNorm over the last dim (vit_seg_modeling.py:172-173,232; eps 1e-6) and backward. */
+int umi_ln_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean, float* rstd,
+               long M, int C, float eps, int dtype, umi_stream_t stream);
+size_t umi_ln_bwd_ws_bytes(long M, int C);
+int umi_ln_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
+               void* dx, int lddx, float* dgamma, float* dbeta, float out_scale, long M, int C, int dtype,
+               void* ws, size_t ws_bytes, umi_stream_t stream);
+
+/* Elementwise: mode 0 y = gelu(x) (exact erf form, vit_seg_modeling.py:115); 1 y = g * gelu'(x); 2 y = x + g;
+ * 3 y = x + g[row % bcast_rows] (position embedding, vit_seg_modeling.py:163). */
+int umi_elementwise(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C,
+                    long bcast_rows, int dtype, umi_stream_t stream);
+
+/* Dropout (vit_seg_modeling.py:103,151): forward writes a byte mask (own counter-based RNG stream), backward reuses it. */
+int umi_dropout(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
+                int dtype, umi_stream_t stream);
+
+/* Multi-head softmax attention (vit_seg_modeling.py:73-91): q,k,v,o are [B, N, heads*D] token tensors (row stride ld),
+ * head h = channels [h*D, (h+1)*D); softmax(q k^T / sqrt(D)) v.  lse/delta: [B*heads*N] fp32 scratch kept for backward. */
+int umi_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse, int B, int N, int heads,
+                 int D, int dtype, umi_stream_t stream);
+int umi_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, const void* dO, int ldo,
+                 const float* lse, void* dq, void* dk, void* dv, int ldd, float* delta, int B, int N, int heads, int D,
+                 int dtype, umi_stream_t stream);
+
+/* UpsamplingBilinear2d(scale_factor=2), align_corners=True (vit_seg_modeling.py:307): forward x[N,H,W,C] -> y[N,2H,2W,C];
+ * backward (x = dy [N,2H,2W,C]) -> y = dx [N,H,W,C] (deterministic gather form). */
+int umi_bilinear2x(const void* x, int ldx, const void* tx, void* y, int ldy, int backward, int N, int H, int W, int C,
+                   int dtype, umi_stream_t stream);   /* tx: consumer transform of x, forward only (nullable) */
 
 #ifdef __cplusplus
 }

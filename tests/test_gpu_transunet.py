@@ -1,0 +1,152 @@
+"""TransUNet (R50-ViT hybrid) on the HIP path vs fixtures of the reference itself and vs the CPU oracle.
+
+Config objects: product `TransUnet.vit_seg_configs.ConfigDict` built from the oracle's plain dict, so both sides
+describe the same network.  Dropout is 0.0 in the parity configs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe, ref_transunet, ref_unet
+from tests.test_oracle_golden import _sig_close, sig
+
+DEV = "cuda"
+
+
+def product_config(cfg, img):
+    from TransUnet.vit_seg_configs import ConfigDict
+    g = img // 16
+    return ConfigDict(patches={"size": (16, 16), "grid": (g, g)}, hidden_size=cfg["hidden_size"],
+                      transformer=dict(mlp_dim=cfg["mlp_dim"], num_heads=cfg["num_heads"], num_layers=cfg["num_layers"],
+                                       attention_dropout_rate=cfg["attention_dropout_rate"], dropout_rate=cfg["dropout_rate"]),
+                      classifier="seg", representation_size=None, decoder_channels=tuple(cfg["decoder_channels"]),
+                      n_classes=cfg["n_classes"], activation="softmax",
+                      resnet=dict(num_layers=tuple(cfg["resnet_layers"]), width_factor=cfg["width_factor"]),
+                      skip_channels=list(cfg["skip_channels"]), n_skip=cfg["n_skip"])
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_product_transunet_surface_and_init(golden_dir):
+    """CPU: constructor, key set/order and init RNG stream equal the reference's (fixture `keys`, `init_sig.*`)."""
+    from TransUnet.vit_seg_modeling import CONFIGS, VisionTransformer
+    g = np.load(os.path.join(golden_dir, "transunet_small.npz"))
+    cfg = ref_transunet.small_config(2)
+    torch.manual_seed(0)
+    m = VisionTransformer(product_config(cfg, 64), img_size=64, num_classes=2)
+    assert list(m.state_dict().keys()) == g["keys"].tolist()
+    if "init_sig." + g["keys"][0] in g:
+        for k, v in m.state_dict().items():
+            _sig_close(sig(v.float()), g["init_sig." + k], rtol=1e-6)
+    assert CONFIGS["R50-ViT-B_16"].n_skip == 3 and CONFIGS["R50-ViT-B_16"].patches.grid == (16, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 64, 64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,ncls", [("transunet_small", 2), ("transunet_small_rgb4", 4)])
+def test_transunet_small_fp32_parity(golden_dir, name, ncls):
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    import loss as L
+    from TransUnet.vit_seg_modeling import VisionTransformer
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = ref_transunet.small_config(ncls)
+    img, B, cin, seed = int(g["img"]), int(g["B"]), int(g["cin"]), int(g["seed"])
+    ref = ref_transunet.RefTransUNet(cfg, img)
+    ref.load_state_dict(recipe.fill_state_dict(ref.state_dict(), seed=seed, negative_gamma=False))
+    x, lab = recipe.synthetic_batch(B, cin, img, img, ncls, seed=seed)
+    L.CLASS_NUMBER = ncls
+    m = VisionTransformer(product_config(cfg, img), img_size=img, num_classes=ncls, compute_dtype="fp32")
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).train()
+    logits = m(x.to(DEV))
+    loss = L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc")
+    loss.backward()
+    gl = g["logits"]
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), gl, rtol=1e-4, atol=1e-4 * float(np.abs(gl).max()))
+    assert abs(loss.item() - float(g["loss0"])) < 2e-5
+    ref.train()
+    rl = ref_unet.dice_bce_mc(ref(x), lab, ncls)
+    rl.backward()
+    worst = ("", 0.0)
+    for (k, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, k
+        # key biases have a mathematically zero gradient (softmax is shift invariant): absolute floor 1e-6
+        e = (p.grad.detach().double().cpu() - rp.grad.double()).norm().item() / (rp.grad.double().norm().item() + 1e-6 / 3e-3)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    assert worst[1] < 3e-3, worst
+    # BatchNorm running stats after one step, eval-mode forward
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert rel_err(v, ref.state_dict()[k]) < 1e-4, k
+    m.eval()
+    ref.eval()
+    with torch.no_grad():
+        ev, rev = m(x.to(DEV)), ref(x)
+    assert ((ev.cpu() - rev).abs().max() / rev.abs().max()).item() < 2e-4
+
+
+@pytest.mark.gpu
+def test_transunet_r50_vit_b16_224_fp32(golden_dir):
+    """Full R50-ViT-B/16 @224 (config 4 shape, B=1): logits signature, loss and per-parameter grad norms vs the reference."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    import loss as L
+    from TransUnet.vit_seg_modeling import VisionTransformer
+    g = np.load(os.path.join(golden_dir, "transunet_r50_b16_224.npz"))
+    cfg = ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)
+    L.CLASS_NUMBER = 2
+    m = VisionTransformer(product_config(cfg, 224), img_size=224, num_classes=2, compute_dtype="fp32")
+    assert len(m.state_dict()) == 409
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=int(g["seed"]), negative_gamma=False))
+    m.to(DEV).train()
+    x, lab = recipe.synthetic_batch(1, 1, 224, 224, 2, seed=int(g["seed"]))
+    logits = m(x.to(DEV))
+    loss = L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc")
+    loss.backward()
+    s = sig(logits.cpu())
+    np.testing.assert_allclose(s[[0, 2]], g["logits_sig"][[0, 2]], rtol=2e-4)
+    np.testing.assert_allclose(s[3:], g["logits_sig"][3:], rtol=1e-3, atol=1e-3 * s[0] / 300)
+    assert abs(loss.item() - float(g["loss0"])) < 2e-5
+    bad = []
+    for k, p in m.named_parameters():
+        ref_norm = float(g["grad_sig." + k][0])
+        if ref_norm < 1e-7:              # e.g. key biases: mathematically zero gradient, pure rounding noise
+            continue
+        if abs(p.grad.double().norm().item() - ref_norm) > 1e-2 * ref_norm:
+            bad.append((k, p.grad.double().norm().item(), ref_norm))
+    assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+def test_transunet_small_fp16_runs_close(golden_dir):
+    """fp16 storage: logits within 3e-2 of logit scale of the fp32 reference, finite grads, cosine > 0.9 on big tensors."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    import loss as L
+    from TransUnet.vit_seg_modeling import VisionTransformer
+    g = np.load(os.path.join(golden_dir, "transunet_small.npz"))
+    cfg = ref_transunet.small_config(2)
+    ref = ref_transunet.RefTransUNet(cfg, 64)
+    ref.load_state_dict(recipe.fill_state_dict(ref.state_dict(), seed=int(g["seed"]), negative_gamma=False))
+    x, lab = recipe.synthetic_batch(2, 1, 64, 64, 2, seed=int(g["seed"]))
+    L.CLASS_NUMBER = 2
+    m = VisionTransformer(product_config(cfg, 64), img_size=64, num_classes=2, compute_dtype="fp16")
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).train()
+    logits = m(x.to(DEV))
+    L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc").backward()
+    gl = torch.from_numpy(g["logits"])
+    assert ((logits.detach().cpu() - gl).abs().max() / gl.abs().max()).item() < 3e-2
+    ref.train()
+    ref_unet.dice_bce_mc(ref(x), lab, 2).backward()
+    for (k, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters()):
+        assert torch.isfinite(p.grad).all(), k
+        if rp.numel() >= 4096 and rp.grad.norm() > 1e-8:
+            c = (p.grad.cpu().flatten().double() @ rp.grad.flatten().double() / (p.grad.norm().cpu().double() * rp.grad.norm().double())).item()
+            assert c > 0.9, (k, c)

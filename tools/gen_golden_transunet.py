@@ -32,6 +32,8 @@ def _case(vsm, loss_mod, sig, meta, GOLD, name, cfg, img, B, cin, seed, full):
     m = vsm.VisionTransformer(_ref_config(cfg, img), img_size=img, num_classes=cfg["n_classes"])
     out = dict(img=img, B=B, cin=cin, seed=seed, n_keys=len(m.state_dict()))
     out["keys"] = np.array(list(m.state_dict().keys()))
+    for k, v in m.state_dict().items():                # the reference's own init under torch.manual_seed(0)
+        out["init_sig." + k] = sig(v.float())
     m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed, negative_gamma=False))
     x, lab = recipe.synthetic_batch(B, cin, img, img, cfg["n_classes"], seed=seed)
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)

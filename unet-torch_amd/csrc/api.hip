@@ -86,6 +86,14 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
     if (!x || !wp || !y || N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
         Ho <= 0 || Wo <= 0 || ldx < Ci || ldy < Co || out_H <= 0 || out_W <= 0)
         return UMI_ERR_BADARG;
+    if (flags & UMI_CONV_DGRAD_STRIDED) {
+        // x = dy of a strided conv (H x W), output grid = the conv's input image (Ho x Wo)
+        if (flags & UMI_CONV_UPSAMPLE2) return UMI_ERR_BADARG;
+        if (H != (Ho + 2 * pad - R) / stride + 1 || W != (Wo + 2 * pad - S) / stride + 1) return UMI_ERR_BADARG;
+        if (out_H != Ho || out_W != Wo || off_h || off_w || stat_part) return UMI_ERR_BADARG;
+        return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
+                                    off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);
+    }
     if (!(flags & UMI_CONV_UPSAMPLE2)) {
         if (Ho != (H + 2 * pad - R) / stride + 1 || Wo != (W + 2 * pad - S) / stride + 1) return UMI_ERR_BADARG;
         if (out_H != Ho || out_W != Wo || off_h || off_w) return UMI_ERR_BADARG;

@@ -78,7 +78,7 @@ extern "C" int umi_pack_kn8(const float* src, void* dst, int T, int K, int N, lo
 // ------------------------------------------------------------------------------------------
 constexpr int GBP = 64, GBC = 64, GBK = 16;
 
-template <typename TI, typename TO, bool UPS>
+template <typename TI, typename TO, bool UPS, bool DGS = false>
 __global__ __launch_bounds__(256) void conv_generic_kernel(
     const TI* __restrict__ x, int ldx, const float4* __restrict__ tx, const TI* __restrict__ wp,
     const float* __restrict__ bias, TO* __restrict__ y, int ldy, float* __restrict__ part,
@@ -118,13 +118,22 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(
     const int tap_hi = UPS ? blockIdx.z + 1 : R * S;
     for (int tap = tap_lo; tap < tap_hi; ++tap) {
         int hi, wi;
+        bool ok = true;
         if (UPS) { hi = ho; wi = wo; }
-        else {
+        else if (DGS) {
+            // data gradient of a strided conv: "output" pixel (ho,wo) is an INPUT-image pixel; it receives
+            // dy[(ho+pad-r)/stride, (wo+pad-s)/stride] through tap (r,s) when the division is exact
+            int r = tap / S, s = tap - r * S;
+            int a = ho + pad - r, b = wo + pad - s;
+            ok = a >= 0 && b >= 0 && (a % stride) == 0 && (b % stride) == 0;
+            hi = a / stride;
+            wi = b / stride;
+        } else {
             int r = tap / S, s = tap - r * S;
             hi = ho * stride - pad + r;
             wi = wo * stride - pad + s;
         }
-        const bool inb = pv && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        const bool inb = pv && ok && hi >= 0 && hi < H && wi >= 0 && wi < W;
         const TI* xp = x + ((long)((long)n * H + hi) * W + wi) * ldx;
         for (int k0 = 0; k0 < Ci; k0 += GBK) {
 #pragma unroll
@@ -213,9 +222,23 @@ int umi_conv_fwd_generic(const void* x, int ldx, const void* tx, const void* wp,
                          int Ho, int Wo, int off_h, int off_w, int out_H, int out_W, int in_dtype, int out_dtype,
                          int flags, hipStream_t s) {
     const bool ups = flags & UMI_CONV_UPSAMPLE2;
+    const bool dgs = flags & UMI_CONV_DGRAD_STRIDED;
     if (ups && (R != 2 || S != 2 || stat_part)) return UMI_ERR_BADARG;
     long P = (long)N * Ho * Wo;
     dim3 grid(umi_cdiv(P, GBP), umi_cdiv(Co, GBC), ups ? 4 : 1), block(256);
+    if (dgs) {
+        if (ups || stat_part) return UMI_ERR_BADARG;
+#define LAUNCHD(TI, TO)                                                                                          \
+    hipLaunchKernelGGL((conv_generic_kernel<TI, TO, false, true>), grid, block, 0, s, (const TI*)x, ldx,          \
+                       (const float4*)tx, (const TI*)wp, bias, (TO*)y, ldy, stat_part, N, H, W, Ci, Co, R, S,     \
+                       stride, pad, Ho, Wo, off_h, off_w, out_H, out_W)
+        if (in_dtype == UMI_F32 && out_dtype == UMI_F32) LAUNCHD(float, float);
+        else if (in_dtype == UMI_F16 && out_dtype == UMI_F16) LAUNCHD(half_t, half_t);
+        else return UMI_ERR_UNSUPPORTED;
+#undef LAUNCHD
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
 #define LAUNCH(TI, TO, U)                                                                                        \
     hipLaunchKernelGGL((conv_generic_kernel<TI, TO, U>), grid, block, 0, s, (const TI*)x, ldx, (const float4*)tx, \
                        (const TI*)wp, bias, (TO*)y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,   \
@@ -459,6 +482,10 @@ __global__ __launch_bounds__(256) void reduce_rows2_kernel(const float* __restri
         out0[c] = (float)(sh[0][0] * (double)scale);
         if (out1) out1[c] = (float)(sh[1][0] * (double)scale);
     }
+}
+
+void umi_launch_reduce_rows2(const float* ws, int rows, int C, float* out0, float* out1, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, ws, rows, C, out0, out1, scale);
 }
 
 template <typename T>

@@ -1,0 +1,302 @@
+"""Tape ops of the TransUNet path (R50 hybrid ResNetV2 + ViT encoder + CUP decoder) on libunetmi kernels.
+
+Extends umi/graph.py's `Tape`.  Token tensors [B, N, C] are carried as NHWC [B, 1, N, C] so that `nn.Linear` is a
+1x1 convolution on the same kernels.  Values produced here are stored *activated* (plain `Act`, tx = None); only the
+decoder's conv+BatchNorm+ReLU layers keep the lazy consumer-side transform of the U-Net path.
+
+Reference semantics (TransUnet/): StdConv2d resnet_skip.py:18-25, PreActBottleneck :38-74, ResNetV2 :112-160,
+Embeddings vit_seg_modeling.py:122-165, Attention :50-94, Mlp :97-119, Block :168-187, DecoderBlock :284-315.
+"""
+import torch
+
+from . import lib as L
+from . import ops, ops_tu
+from .graph import Act, Tape, _wants_grad
+
+
+class TUTape(Tape):
+    def __init__(self, *a, seed=0, **k):
+        super().__init__(*a, **k)
+        self._seed = int(seed)
+        self._drop_count = 0
+
+    # gradients of a value with several consumers are summed by a libunetmi kernel (no torch arithmetic)
+    def _give(self, act, g):
+        if act.parts is None and act.needs_grad and act.grad is not None:
+            ops_tu.add(act.grad, g, act.grad)
+            return
+        super()._give(act, g)
+
+    # ---- convolution with weight standardisation (no bias), output stored raw == activated -----------------------
+    def std_conv(self, a: Act, conv):
+        w = conv.weight
+        Co, Ci, R, S = w.shape
+        stride, pad = conv.stride[0], conv.padding[0]
+        N, H, W, Ca = a.shape
+        assert Ca == Ci
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        out = self.alloc(N, Ho, Wo, Co, device=a.raw.device)
+        ws, rstd = ops_tu.wstd_fwd(w, 1e-5)
+        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(ws, self.dtype, k8=bool(lay)), None, out, R, S, stride, pad)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                gws = torch.empty_like(ws)
+                ops.conv_wgrad(a.raw, a.tx, o.grad, None, gws, Ci * R * S, R * S, 1, self.inv, R, S, stride, pad)
+                self._set_pgrad(w, ops_tu.wstd_bwd(ws, rstd, gws))
+                if _wants_grad(a):
+                    dx = self.alloc(N, H, W, Ci, device=out.device)
+                    if stride == 1:
+                        ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(ws, self.dtype, k8=bool(lay)), None, dx,
+                                     R, S, 1, R - 1 - pad)
+                    else:
+                        wpd = ops_tu.pack_conv_dgrad_strided(ws, self.dtype)
+                        self._strided_dgrad(o.grad, wpd, dx, R, S, stride, pad)
+                    self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    @staticmethod
+    def _strided_dgrad(dy, wpd, dx, R, S, stride, pad):
+        N, Hd, Wd, Cd, lddy = ops._nhwc(dy)
+        _, Hx, Wx, Cx, lddx = ops._nhwc(dx)
+        L.check(L.fn("umi_conv_fwd")(dy.data_ptr(), lddy, None, wpd.data_ptr(), None, dx.data_ptr(), lddx, None,
+                                     N, Hd, Wd, Cd, Cx, R, S, stride, pad, Hx, Wx, 0, 0, Hx, Wx, ops._dt(dy), ops._dt(dx),
+                                     L.CONV_DGRAD_STRIDED | L.CONV_UPSAMPLE2 * 0, ops._stream()), "umi_conv_fwd(dgrad strided)")
+
+    # ---- GroupNorm (+ residual) (+ ReLU) ---------------------------------------------------------------------------
+    def group_norm(self, a: Act, gn, relu, residual: Act = None):
+        assert a.tx is None and (residual is None or residual.tx is None)
+        N, H, W, C = a.shape
+        out = self.alloc(N, H, W, C, device=a.raw.device)
+        g32, b32 = gn.weight.detach().float(), gn.bias.detach().float()
+        mean, rstd = ops_tu.gn_fwd(a.raw, g32, b32, gn.num_groups, gn.eps, relu, residual.raw if residual is not None else None, out)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                dx = self.alloc(N, H, W, C, device=out.device)
+                dres = self.alloc(N, H, W, C, device=out.device) if (residual is not None and _wants_grad(residual)) else None
+                dg, db = ops_tu.gn_bwd(o.grad, out, a.raw, mean, rstd, g32, gn.num_groups, relu, dx, dres, self.inv)
+                self._set_pgrad(gn.weight, dg)
+                self._set_pgrad(gn.bias, db)
+                if dres is not None:
+                    self._give(residual, dres)
+                self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def pool3s2(self, a: Act):
+        N, H, W, C = a.shape
+        out = self.alloc(N, (H - 3) // 2 + 1, (W - 3) // 2 + 1, C, device=a.raw.device)
+        ops_tu.pool3s2_fwd(a.raw, out)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None or not _wants_grad(a):
+                    return
+                dx = self.alloc(N, H, W, C, device=out.device)
+                ops_tu.pool3s2_bwd(o.grad, a.raw, dx)
+                self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def pad_to(self, a: Act, size):
+        """Zero-padded top-left copy (resnet_skip.py:150-155)."""
+        N, H, W, C = a.shape
+        if H == size and W == size:
+            return a
+        out = self.alloc(N, size, size, C, zero=True, device=a.raw.device)
+        out[:, :H, :W, :].copy_(a.raw)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is not None:
+                    self._give(a, o.grad[:, :H, :W, :].contiguous())
+            self.steps.append(bwd)
+        return o
+
+    # ---- token ops -----------------------------------------------------------------------------------------------------
+    def linear(self, a: Act, weight, bias):
+        """nn.Linear ([Co,Ci] weight) or a 1x1 Conv2d ([Co,Ci,1,1] weight) + bias on [B,1,N,Cin] tokens / NHWC maps."""
+        Co, Ci = weight.shape[0], weight.shape[1]
+        N, H, W, Ca = a.shape
+        assert Ca == Ci
+        out = self.alloc(N, H, W, Co, device=a.raw.device)
+        w4 = weight.detach().float().reshape(Co, Ci, 1, 1)
+        b32 = bias.detach().float() if bias is not None else None
+        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(w4, self.dtype, k8=bool(lay)), b32, out, 1, 1, 1, 0)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                gw = self._new_pgrad(weight)
+                ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci, 1, 1, self.inv, 1, 1, 1, 0)
+                self._set_pgrad(weight, gw)
+                if bias is not None:
+                    gb = self._new_pgrad(bias)
+                    ops.colsum(o.grad, gb, self.inv)
+                    self._set_pgrad(bias, gb)
+                if _wants_grad(a):
+                    dx = self.alloc(N, H, W, Ci, device=out.device)
+                    ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(w4, self.dtype, k8=bool(lay)), None, dx, 1, 1, 1, 0)
+                    self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def conv1x1_bias(self, a: Act, conv):
+        """Patch embedding: Conv2d(k=1) + bias (vit_seg_modeling.py:145-148)."""
+        return self.linear(a, conv.weight, conv.bias)
+
+    def layer_norm(self, a: Act, ln):
+        N, H, W, C = a.shape
+        out = self.alloc(N, H, W, C, device=a.raw.device)
+        g32, b32 = ln.weight.detach().float(), ln.bias.detach().float()
+        mean, rstd = ops_tu.ln_fwd(a.raw, g32, b32, ln.eps, out)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                dx = self.alloc(N, H, W, C, device=out.device)
+                dg, db = ops_tu.ln_bwd(o.grad, a.raw, g32, mean, rstd, dx, self.inv)
+                self._set_pgrad(ln.weight, dg)
+                self._set_pgrad(ln.bias, db)
+                self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def gelu(self, a: Act):
+        out = torch.empty_like(a.raw)
+        ops_tu.gelu_fwd(a.raw, out)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                dx = torch.empty_like(a.raw)
+                ops_tu.gelu_bwd(a.raw, o.grad, dx)
+                self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def add(self, a: Act, b: Act):
+        out = torch.empty_like(a.raw)
+        ops_tu.add(a.raw, b.raw, out)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                # both addends receive the same gradient; the second gets its own copy so later in-place accumulation
+                # into one cannot alias the other
+                self._give(a, o.grad)
+                self._give(b, o.grad.clone())
+            self.steps.append(bwd)
+        return o
+
+    def add_position(self, a: Act, pos):
+        """tokens + position_embeddings [1, N, C] (vit_seg_modeling.py:163)."""
+        B, _, N, C = a.shape
+        out = torch.empty_like(a.raw)
+        p = pos.detach().reshape(N, C).to(self.dtype).contiguous()
+        ops_tu.add_bcast(a.raw, p, out, N)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                gp = torch.empty(N * C, dtype=torch.float32, device=out.device)
+                ops.colsum(o.grad.reshape(1, 1, B, N * C), gp, self.inv)
+                self._set_pgrad(pos, gp.view_as(pos))
+                self._give(a, o.grad)
+            self.steps.append(bwd)
+        return o
+
+    def dropout(self, a: Act, p):
+        if not self.training or p <= 0.0:
+            return a
+        out = torch.empty_like(a.raw)
+        mask = torch.empty(a.raw.numel(), dtype=torch.uint8, device=a.raw.device)
+        self._drop_count += 1
+        ops_tu.dropout(a.raw, out, mask, False, p, self._seed * 7919 + self._drop_count)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                dx = torch.empty_like(a.raw)
+                ops_tu.dropout(o.grad, dx, mask, True, p, 0)
+                self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def attention(self, q: Act, k: Act, v: Act, heads):
+        out = torch.empty_like(q.raw)
+        lse = ops_tu.attn_fwd(q.raw, k.raw, v.raw, out, heads)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                dq, dk, dv = torch.empty_like(q.raw), torch.empty_like(q.raw), torch.empty_like(q.raw)
+                ops_tu.attn_bwd(q.raw, k.raw, v.raw, out, o.grad, lse, dq, dk, dv, heads)
+                self._give(q, dq)
+                self._give(k, dk)
+                self._give(v, dv)
+            self.steps.append(bwd)
+        return o
+
+    # ---- decoder -------------------------------------------------------------------------------------------------------
+    def bilinear2x_into(self, a: Act, dest):
+        """UpsamplingBilinear2d(x2, align_corners=True) of the *activated* `a`, written into `dest` (a channel slice)."""
+        N, H, W, C = a.shape
+        assert tuple(dest.shape) == (N, 2 * H, 2 * W, C)
+        ops_tu.bilinear2x(a.raw, dest, False, a.tx)
+        o = Act(dest, None)
+        if self.record:
+            def bwd():
+                if o.grad is None or not _wants_grad(a):
+                    return
+                dx = self.alloc(N, H, W, C, device=dest.device)
+                ops_tu.bilinear2x(o.grad, dx, True)
+                self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
+    def copy_into(self, a: Act, dest):
+        """Place a stored-activated tensor into a channel slice of a concat buffer."""
+        assert a.tx is None
+        dest.copy_(a.raw)
+        o = Act(dest, None)
+        if self.record:
+            def bwd():
+                if o.grad is not None:
+                    self._give(a, o.grad.contiguous())
+            self.steps.append(bwd)
+        return o
+
+    def tokens_to_map(self, a: Act, h, w):
+        """[B,1,N,C] tokens -> [B,h,w,C] feature map: a free view in NHWC (vit_seg_modeling.py:356-359)."""
+        B, _, N, C = a.shape
+        o = Act(a.raw.view(B, h, w, C), None)
+        if self.record:
+            def bwd():
+                if o.grad is not None:
+                    self._give(a, o.grad.reshape(B, 1, N, C))
+            self.steps.append(bwd)
+        return o
+
+    def map_to_tokens(self, a: Act):
+        N, H, W, C = a.shape
+        o = Act(a.raw.view(N, 1, H * W, C), None)
+        if self.record:
+            def bwd():
+                if o.grad is not None:
+                    self._give(a, o.grad.reshape(N, H, W, C))
+            self.steps.append(bwd)
+        return o

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_
 from . import build as _build
 
 UMI_F32, UMI_F16 = 0, 1
-CONV_UPSAMPLE2, CONV_FORCE_GENERIC = 1, 2
+CONV_UPSAMPLE2, CONV_FORCE_GENERIC, CONV_DGRAD_STRIDED = 1, 2, 4
 
 _ERR = {-1: "UMI_ERR_BADARG", -2: "UMI_ERR_UNSUPPORTED", -3: "UMI_ERR_WORKSPACE"}
 
@@ -58,6 +58,29 @@ SIGNATURES = {
                                c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "umi_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
     "umi_materialize_nchw": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_wstd_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "umi_wstd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "umi_gn_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                           c_int, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    "umi_gn_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "umi_gn_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                           c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_long, c_int, c_int, c_int,
+                           c_void_p, c_size_t, c_void_p]),
+    "umi_pool3s2_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_pool3s2_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_ln_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, c_float,
+                           c_int, c_void_p]),
+    "umi_ln_bwd_ws_bytes": (c_size_t, [c_long, c_int]),
+    "umi_ln_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                           c_float, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umi_elementwise": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_long, c_int, c_void_p]),
+    "umi_dropout": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_float, ctypes.c_uint, c_long, c_int, c_int,
+                            c_void_p]),
+    "umi_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                             c_void_p]),
+    "umi_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_bilinear2x": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_colsum": (c_int, [c_void_p, c_int, c_void_p, c_float, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
 }
 

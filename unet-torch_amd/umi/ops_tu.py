@@ -1,0 +1,154 @@
+"""Tensor-level wrappers for the TransUNet kernels of libunetmi (see include/unetmi.h, 'TransUNet path')."""
+import torch
+
+from . import lib as L
+from .ops import _dt, _nhwc, _ptr, _stream, workspace, pack_kn
+
+
+def _rows(t):
+    """[N,H,W,C] view -> (M rows, C, ld)."""
+    N, H, W, C, ld = _nhwc(t)
+    return N * H * W, C, ld
+
+
+def wstd_fwd(w, eps=1e-5):
+    Co = w.shape[0]
+    K = w[0].numel()
+    wf = w.detach().float().contiguous()
+    ws = torch.empty_like(wf)
+    rstd = torch.empty(Co, dtype=torch.float32, device=w.device)
+    L.check(L.fn("umi_wstd_fwd")(wf.data_ptr(), ws.data_ptr(), rstd.data_ptr(), Co, K, eps, _stream()), "umi_wstd_fwd")
+    return ws, rstd
+
+
+def wstd_bwd(ws, rstd, g):
+    dw = torch.empty_like(ws)
+    L.check(L.fn("umi_wstd_bwd")(ws.data_ptr(), rstd.data_ptr(), g.data_ptr(), dw.data_ptr(), ws.shape[0], ws[0].numel(),
+                                 _stream()), "umi_wstd_bwd")
+    return dw
+
+
+def gn_fwd(x, gamma, beta, groups, eps, relu, res, y):
+    N, H, W, C, ldx = _nhwc(x)
+    _, _, _, _, ldy = _nhwc(y)
+    mean = torch.empty(N * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    ldr = _nhwc(res)[4] if res is not None else 0
+    L.check(L.fn("umi_gn_fwd")(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(res), ldr, y.data_ptr(), ldy,
+                               mean.data_ptr(), rstd.data_ptr(), int(relu), N, H * W, C, groups, eps, _dt(x), _stream()),
+            "umi_gn_fwd")
+    return mean, rstd
+
+
+def gn_bwd(dy, y, x, mean, rstd, gamma, groups, relu, dx, dres, out_scale):
+    N, H, W, C, ldx = _nhwc(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    ws = workspace(L.fn("umi_gn_bwd_ws_bytes")(N, C, groups), x.device)
+    L.check(L.fn("umi_gn_bwd")(dy.data_ptr(), _nhwc(dy)[4], y.data_ptr(), _nhwc(y)[4], x.data_ptr(), ldx, mean.data_ptr(),
+                               rstd.data_ptr(), gamma.data_ptr(), int(relu), dx.data_ptr(), _nhwc(dx)[4], _ptr(dres),
+                               _nhwc(dres)[4] if dres is not None else 0, dg.data_ptr(), db.data_ptr(), out_scale, N, H * W,
+                               C, groups, _dt(x), ws.data_ptr(), ws.numel(), _stream()), "umi_gn_bwd")
+    return dg, db
+
+
+def pool3s2_fwd(x, y):
+    N, H, W, C, ldx = _nhwc(x)
+    L.check(L.fn("umi_pool3s2_fwd")(x.data_ptr(), ldx, y.data_ptr(), _nhwc(y)[4], N, H, W, C, _dt(x), _stream()),
+            "umi_pool3s2_fwd")
+
+
+def pool3s2_bwd(dy, x, dx):
+    N, H, W, C, ldx = _nhwc(x)
+    L.check(L.fn("umi_pool3s2_bwd")(dy.data_ptr(), _nhwc(dy)[4], x.data_ptr(), ldx, dx.data_ptr(), _nhwc(dx)[4], N, H, W, C,
+                                    _dt(x), _stream()), "umi_pool3s2_bwd")
+
+
+def ln_fwd(x, gamma, beta, eps, y):
+    M, C, ldx = _rows(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    L.check(L.fn("umi_ln_fwd")(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _rows(y)[2],
+                               mean.data_ptr(), rstd.data_ptr(), M, C, eps, _dt(x), _stream()), "umi_ln_fwd")
+    return mean, rstd
+
+
+def ln_bwd(dy, x, gamma, mean, rstd, dx, out_scale):
+    M, C, ldx = _rows(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    ws = workspace(L.fn("umi_ln_bwd_ws_bytes")(M, C), x.device)
+    L.check(L.fn("umi_ln_bwd")(dy.data_ptr(), _rows(dy)[2], x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
+                               rstd.data_ptr(), dx.data_ptr(), _rows(dx)[2], dg.data_ptr(), db.data_ptr(), out_scale, M, C,
+                               _dt(x), ws.data_ptr(), ws.numel(), _stream()), "umi_ln_bwd")
+    return dg, db
+
+
+def elementwise(mode, x, g, y, bcast_rows=0):
+    M, C, ldx = _rows(x)
+    ldg = 0
+    if g is not None:
+        ldg = g.stride(-2) if g.dim() >= 2 else C
+    L.check(L.fn("umi_elementwise")(mode, x.data_ptr(), ldx, _ptr(g), ldg, y.data_ptr(), _rows(y)[2], M, C, bcast_rows,
+                                    _dt(x), _stream()), "umi_elementwise")
+
+
+def gelu_fwd(x, y):
+    elementwise(0, x, None, y)
+
+
+def gelu_bwd(pre, g, y):
+    elementwise(1, pre, g, y)
+
+
+def add(a, b, y):
+    elementwise(2, a, b, y)
+
+
+def add_bcast(a, rows_tensor, y, bcast_rows):
+    elementwise(3, a, rows_tensor, y, bcast_rows)
+
+
+def dropout(x, y, mask, backward, p, seed):
+    M, C, ldx = _rows(x)
+    L.check(L.fn("umi_dropout")(x.data_ptr(), ldx, y.data_ptr(), _rows(y)[2], mask.data_ptr(), int(backward), p,
+                                seed & 0xFFFFFFFF, M, C, _dt(x), _stream()), "umi_dropout")
+
+
+def attn_fwd(q, k, v, o, heads):
+    B, _, N, C = q.shape
+    D = C // heads
+    ld = _nhwc(q)[4]
+    assert _nhwc(k)[4] == ld and _nhwc(v)[4] == ld
+    lse = torch.empty(B * heads * N, dtype=torch.float32, device=q.device)
+    L.check(L.fn("umi_attn_fwd")(q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, o.data_ptr(), _nhwc(o)[4], lse.data_ptr(), B,
+                                 N, heads, D, _dt(q), _stream()), "umi_attn_fwd")
+    return lse
+
+
+def attn_bwd(q, k, v, o, dO, lse, dq, dk, dv, heads):
+    B, _, N, C = q.shape
+    D = C // heads
+    ld, ldo, ldd = _nhwc(q)[4], _nhwc(o)[4], _nhwc(dq)[4]
+    assert _nhwc(dO)[4] == ldo and _nhwc(dk)[4] == ldd and _nhwc(dv)[4] == ldd
+    delta = torch.empty_like(lse)
+    L.check(L.fn("umi_attn_bwd")(q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, o.data_ptr(), dO.data_ptr(), ldo,
+                                 lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ldd, delta.data_ptr(), B, N,
+                                 heads, D, _dt(q), _stream()), "umi_attn_bwd")
+
+
+def bilinear2x(x, y, backward=False, tx=None):
+    if backward:                  # x = dy [N,2H,2W,C], y = dx [N,H,W,C]
+        N, H, W, C, ldy = _nhwc(y)
+        ldx = _nhwc(x)[4]
+    else:
+        N, H, W, C, ldx = _nhwc(x)
+        ldy = _nhwc(y)[4]
+    L.check(L.fn("umi_bilinear2x")(x.data_ptr(), ldx, _ptr(tx), y.data_ptr(), ldy, int(backward), N, H, W, C, _dt(x), _stream()),
+            "umi_bilinear2x")
+
+
+def pack_conv_dgrad_strided(w, dtype):
+    """OIHW -> [R*S][Co][Ci] unflipped, for UMI_CONV_DGRAD_STRIDED."""
+    Co, Ci, R, S = w.shape
+    return pack_kn(w, R * S, Co, Ci, 1, Ci * R * S, R * S, False, dtype)
