@@ -1,0 +1,168 @@
+"""Kernel-level GPU parity for the TransUNet ops of libunetmi vs plain PyTorch fp32 (CPU)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    from umi import lib, ops, ops_tu
+    return lib, ops, ops_tu
+
+
+def _close(a, b, tol):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert (a - b).abs().max().item() <= tol * (b.abs().max().item() + 1e-12), ((a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3)])
+def test_group_norm_fwd_bwd(dt, tol):
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(1)
+    N, H, W, C, G = 2, 7, 9, 64, 32
+    x = (torch.randn(N, H, W, C, generator=g) * 2 + 0.5).to(dt)
+    res = torch.randn(N, H, W, C, generator=g).to(dt)
+    gamma, beta = 0.5 + torch.rand(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy = torch.randn(N, H, W, C, generator=g).to(dt)
+    xr, rr = x.float().permute(0, 3, 1, 2).requires_grad_(True), res.float().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.relu(F.group_norm(xr, G, gr, br, 1e-6) + rr)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    y = torch.empty(N, H, W, C, device=DEV, dtype=dt)
+    xd, rd = x.to(DEV), res.to(DEV)
+    mean, rstd = T.gn_fwd(xd, gamma.to(DEV), beta.to(DEV), G, 1e-6, True, rd, y)
+    _close(y.permute(0, 3, 1, 2), ref, tol)
+    dx, dres = torch.empty_like(y), torch.empty_like(y)
+    dg, db = T.gn_bwd(dy.to(DEV), y, xd, mean, rstd, gamma.to(DEV), G, True, dx, dres, 0.5)
+    _close(dx.permute(0, 3, 1, 2), xr.grad, 10 * tol)
+    _close(dres.permute(0, 3, 1, 2), rr.grad, 10 * tol)
+    _close(dg, gr.grad * 0.5, 10 * tol)
+    _close(db, br.grad * 0.5, 10 * tol)
+
+
+def test_layer_norm_gelu_pool_bilinear_fp32():
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(2)
+    B, N, C = 2, 37, 96
+    x = torch.randn(B, 1, N, C, generator=g)
+    gamma, beta = 0.5 + torch.rand(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy = torch.randn(B, 1, N, C, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    ref.backward(dy)
+    y = torch.empty_like(x, device=DEV)
+    mean, rstd = T.ln_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, y)
+    _close(y, ref, 2e-5)
+    dx = torch.empty_like(y)
+    dg, db = T.ln_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dx, 1.0)
+    _close(dx, xr.grad, 2e-4); _close(dg, gr.grad, 2e-4); _close(db, br.grad, 2e-4)
+    # GELU
+    u = torch.randn(B, 1, N, C, generator=g) * 2
+    ur = u.clone().requires_grad_(True)
+    F.gelu(ur).backward(dy)
+    o, du = torch.empty_like(y), torch.empty_like(y)
+    T.gelu_fwd(u.to(DEV), o); T.gelu_bwd(u.to(DEV), dy.to(DEV), du)
+    _close(o, F.gelu(u), 2e-6); _close(du, ur.grad, 2e-5)
+    # max-pool 3x3 / s2 / p0 on an odd map
+    xm = torch.randn(2, 15, 17, 8, generator=g)
+    xmr = xm.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    pr = F.max_pool2d(xmr, 3, 2, 0)
+    gp = torch.randn(pr.shape, generator=g)
+    pr.backward(gp)
+    yp = torch.empty(2, 7, 8, 8, device=DEV)
+    T.pool3s2_fwd(xm.to(DEV), yp)
+    _close(yp.permute(0, 3, 1, 2), pr, 0.0)
+    dxp = torch.empty(2, 15, 17, 8, device=DEV)
+    T.pool3s2_bwd(gp.permute(0, 2, 3, 1).contiguous().to(DEV), xm.to(DEV), dxp)
+    _close(dxp.permute(0, 3, 1, 2), xmr.grad, 1e-6)
+    # bilinear x2 align_corners=True with a consumer transform on the input, + adjoint
+    xb = torch.randn(2, 5, 7, 16, generator=g)
+    t = torch.zeros(16, 4); t[:, 1] = 1.5; t[:, 2] = 0.1; t[:, 3] = 0.0
+    act = torch.clamp_min(xb * 1.5 + 0.1, 0.0).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ub = F.interpolate(act, scale_factor=2, mode="bilinear", align_corners=True)
+    gb = torch.randn(ub.shape, generator=g)
+    ub.backward(gb)
+    yb = torch.empty(2, 10, 14, 16, device=DEV)
+    T.bilinear2x(xb.to(DEV), yb, False, t.to(DEV))
+    _close(yb.permute(0, 3, 1, 2), ub, 2e-6)
+    dxb = torch.empty(2, 5, 7, 16, device=DEV)
+    T.bilinear2x(gb.permute(0, 2, 3, 1).contiguous().to(DEV), dxb, True)
+    _close(dxb.permute(0, 3, 1, 2), act.grad, 2e-5)
+
+
+@pytest.mark.parametrize("dt,tol,N,heads,D", [(torch.float32, 2e-5, 50, 4, 16), (torch.float16, 3e-3, 196, 3, 64)])
+def test_attention_fwd_bwd(dt, tol, N, heads, D):
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(3)
+    B, C = 2, heads * D
+    q, k, v = (torch.randn(B, 1, N, C, generator=g).to(dt) for _ in range(3))
+    dO = torch.randn(B, 1, N, C, generator=g).to(dt)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t: t.view(B, N, heads, D).permute(0, 2, 1, 3)
+    p = torch.softmax(sp(qr) @ sp(kr).transpose(-1, -2) / math.sqrt(D), -1)
+    ref = (p @ sp(vr)).permute(0, 2, 1, 3).reshape(B, 1, N, C)
+    ref.backward(dO.float())
+    o = torch.empty(B, 1, N, C, device=DEV, dtype=dt)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    lse = T.attn_fwd(qd, kd, vd, o, heads)
+    _close(o, ref, tol)
+    dq, dk, dv = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)
+    T.attn_bwd(qd, kd, vd, o, dO.to(DEV), lse, dq, dk, dv, heads)
+    _close(dq, qr.grad, 5 * tol); _close(dk, kr.grad, 5 * tol); _close(dv, vr.grad, 5 * tol)
+
+
+def test_wstd_and_strided_dgrad_fp32():
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(24, 16, 3, 3, generator=g)
+    wr = w.clone().requires_grad_(True)
+    v, m = torch.var_mean(wr, dim=[1, 2, 3], keepdim=True, unbiased=False)
+    ws_ref = (wr - m) / torch.sqrt(v + 1e-5)
+    gw = torch.randn(w.shape, generator=g)
+    ws_ref.backward(gw)
+    ws, rstd = T.wstd_fwd(w.to(DEV), 1e-5)
+    _close(ws, ws_ref, 2e-6)
+    _close(T.wstd_bwd(ws, rstd, gw.to(DEV)), wr.grad, 2e-5)
+    # data gradient of a stride-2 3x3 conv (pad 1) and of a stride-2 1x1 conv
+    for R, pad in ((3, 1), (1, 0)):
+        x = torch.zeros(2, 16, 11, 13, requires_grad=True)
+        wc = torch.randn(24, 16, R, R, generator=g) * 0.2
+        y = F.conv2d(x, wc, None, 2, pad)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        dx = torch.empty(2, 11, 13, 16, device=DEV)
+        from umi.graph_tu import TUTape
+        TUTape._strided_dgrad(gy.permute(0, 2, 3, 1).contiguous().to(DEV), T.pack_conv_dgrad_strided(wc.to(DEV), torch.float32),
+                              dx, R, R, 2, pad)
+        _close(dx.permute(0, 3, 1, 2), x.grad, 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2 * 13 * 11, 192, 128), (4704, 768, 768), (300, 256, 128)])
+def test_wgrad1x1_mfma_and_colsum(shape):
+    lib, ops, T = _gpu()
+    M, Ci, Co = shape
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(1, 1, M, Ci, generator=g).half()
+    dy = (torch.randn(1, 1, M, Co, generator=g) * 0.1).half()
+    ref = dy[0, 0].float().t() @ x[0, 0].float()              # [Co, Ci]
+    res = {}
+    for name, flags in (("mfma", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        gw = torch.empty(Co, Ci, device=DEV)
+        ops.conv_wgrad(x.to(DEV), None, dy.to(DEV), None, gw, Ci, 1, 1, 1.0, 1, 1, 1, 0, flags=flags)
+        res[name] = gw.cpu()
+    scale = ref.abs().max().item()
+    assert (res["generic"] - ref).abs().max().item() < 2e-3 * scale
+    assert (res["mfma"] - ref).abs().max().item() < 4e-3 * scale
+    gb = torch.empty(Co, device=DEV)
+    ops.colsum(dy.to(DEV), gb, 0.5)
+    _close(gb, dy[0, 0].float().sum(0) * 0.5, 2e-3)
+    wide = torch.randn(1, 1, 24, 20000, generator=g)          # position-embedding-like: few rows, very wide
+    gp = torch.empty(20000, device=DEV)
+    ops.colsum(wide.to(DEV), gp, 1.0)
+    _close(gp, wide[0, 0].sum(0), 1e-5)

@@ -44,6 +44,11 @@ bool umi_head_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int ld
 size_t umi_head_wgrad_ws_bytes(long P, int Ci, int Co);
 int umi_head_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
                    long s_t, float out_scale, long P, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s);
+bool umi_wgrad1x1_mfma_ok(long M, int Ci, int Co, int R, int S, int stride, int pad, int ldx, int lddy, int dtype, int flags,
+                          const void* txb);
+size_t umi_wgrad1x1_mfma_ws_bytes(long M, int Ci, int Co);
+int umi_wgrad1x1_mfma(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
+                      long s_t, float out_scale, long M, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s);
 bool umi_wgradT_mfma_ok(int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int ldx,
                         int lddy, int dtype, int flags, const void* txa);
 size_t umi_wgradT_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co);
@@ -129,6 +134,10 @@ extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co,
         size_t m = umi_wgrad3x3_mfma_ws_bytes(N, Ho, Wo, Ci, Co);
         if (m > g) g = m;
     }
+    if (umi_wgrad1x1_mfma_ok((long)N * Ho * Wo, Ci, Co, R, S, 1, 0, 8, 8, dtype, flags, nullptr)) {
+        size_t m = umi_wgrad1x1_mfma_ws_bytes((long)N * Ho * Wo, Ci, Co);
+        if (m > g) g = m;
+    }
     if (umi_wgradT_mfma_ok(2 * Ho, 2 * Wo, Ci, Co, R, S, 2, 0, Ho, Wo, 8, 8, dtype, flags, nullptr)) {
         size_t m = umi_wgradT_mfma_ws_bytes(N, Ho, Wo, Ci, Co);
         if (m > g) g = m;
@@ -152,6 +161,9 @@ extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const voi
         return UMI_ERR_BADARG;
     if (umi_wgrad3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, lddy, dtype, flags, txb))
         return umi_wgrad3x3_mfma(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes,
+                                 (hipStream_t)stream);
+    if (umi_wgrad1x1_mfma_ok((long)N * H * W, Ci, Co, R, S, stride, pad, ldx, lddy, dtype, flags, txb))
+        return umi_wgrad1x1_mfma(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, (long)N * H * W, Ci, Co, ws, ws_bytes,
                                  (hipStream_t)stream);
     if (umi_wgradT_mfma_ok(H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, lddy, dtype, flags, txa))
         return umi_wgradT_mfma(x, ldx, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, Ho, Wo, Ci, Co, ws, ws_bytes,

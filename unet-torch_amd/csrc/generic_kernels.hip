@@ -557,47 +557,61 @@ extern "C" int umi_bn_bwd_apply(void* da, int ldda, const void* y, int ldy, cons
 // ------------------------------------------------------------------------------------------
 // per-channel column sum (bias gradients)
 // ------------------------------------------------------------------------------------------
+// 2-D decomposition: block (column tile of 64, row split); thread = (column, 1 of 4 row lanes); partial rows
+// ws[split][2][C] are reduced in fixed order by reduce_rows2_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum1_kernel(const T* __restrict__ x, int ldx, float* __restrict__ ws, long M,
-                                                      int C) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    const int CT = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
-    const int PL = 256 / CT;
-    const int cl = tid % CT, pl = tid / CT;
-    const long r0 = (long)blockIdx.x * BNB_RPB;
-    long r1 = r0 + BNB_RPB;
+                                                      int C, long rows_per_split, float* __restrict__ out, float scale) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    long r1 = r0 + rows_per_split;
     if (r1 > M) r1 = M;
-    for (int cb = 0; cb < C; cb += CT) {
-        int c = cb + cl;
-        float s = 0.f;
-        if (c < C)
-            for (long r = r0 + pl; r < r1; r += PL) s += (float)x[r * ldx + c];
-        red[tid] = s;
-        __syncthreads();
-        if (tid < CT) {
-            float a = 0.f;
-            for (int k = 0; k < PL; ++k) a += red[k * CT + tid];
-            if (cb + tid < C) ws[((long)blockIdx.x * 2 + 0) * C + cb + tid] = a;
-        }
-        __syncthreads();
+    float s = 0.f;
+    if (c < C)
+        for (long r = r0 + rl; r < r1; r += 4) s += (float)x[r * ldx + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        if (gridDim.y == 1) out[c] = t * scale;                       // single split: no second stage
+        else ws[((long)blockIdx.y * 2 + 0) * C + c] = t;
     }
 }
 
-extern "C" size_t umi_colsum_ws_bytes(long M, int C) { return umi_bn_bwd_ws_bytes(M, C); }
+static void colsum_plan(long M, int C, int* splits, long* rps) {
+    long ctiles = (C + 63) / 64;
+    long want = (1024 + ctiles - 1) / ctiles;
+    long maxs = (M + 31) / 32;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    *rps = (M + want - 1) / want;
+    *splits = (int)((M + *rps - 1) / *rps);
+}
+
+extern "C" size_t umi_colsum_ws_bytes(long M, int C) {
+    int splits; long rps;
+    colsum_plan(M, C, &splits, &rps);
+    return (size_t)splits * 2 * (size_t)C * sizeof(float);
+}
 
 extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, long M, int C, int dtype, void* ws,
                           size_t ws_bytes, umi_stream_t stream) {
     if (!x || !out || M <= 0 || C <= 0) return UMI_ERR_BADARG;
     if (ws_bytes < umi_colsum_ws_bytes(M, C)) return UMI_ERR_WORKSPACE;
-    int rows = umi_cdiv(M, BNB_RPB);
+    int splits; long rps;
+    colsum_plan(M, C, &splits, &rps);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == UMI_F32) hipLaunchKernelGGL(colsum1_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)ws, M, C);
-    else if (dtype == UMI_F16) hipLaunchKernelGGL(colsum1_kernel<half_t>, dim3(rows), dim3(256), 0, s, (const half_t*)x, ldx, (float*)ws, M, C);
+    dim3 grid((C + 63) / 64, splits);
+    if (dtype == UMI_F32) hipLaunchKernelGGL(colsum1_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, (float*)ws, M, C, rps, out, out_scale);
+    else if (dtype == UMI_F16) hipLaunchKernelGGL(colsum1_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, ldx, (float*)ws, M, C, rps, out, out_scale);
     else return UMI_ERR_BADARG;
     UMI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, rows, C, out, (float*)nullptr, out_scale);
-    UMI_LAUNCH_CHECK();
+    if (splits > 1) {
+        hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, splits, C, out, (float*)nullptr, out_scale);
+        UMI_LAUNCH_CHECK();
+    }
     return UMI_OK;
 }
 

@@ -329,7 +329,168 @@ void plan(int N, int H, int W, int Ci, int Co, int* tiles_x, int* tiles_y, int* 
     *splits = (*tiles_total + *tps - 1) / *tps;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient of a pointwise conv / nn.Linear:  dW[ci][co] = sum_p tx(x[p])[ci] * dy[p][co]
+// (TransUNet: QKV/out/MLP linears vit_seg_modeling.py:58-62,100-101, patch embedding, bottleneck 1x1 convs).
+// Pixels are linear rows (dense NHWC), K tile = 64 rows.  Block tile TM x TM channels, 2 x 2 waves, each wave
+// (TM/2)^2 = MT x MT accumulator tiles; both operands by transposing LDS reads.
+template <int TM, bool HAS_TX>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __restrict__ x, int ldx,
+                                                               const float4* __restrict__ tx,
+                                                               const half_t* __restrict__ dy, int lddy,
+                                                               float* __restrict__ part, long M, int Ci, int Co,
+                                                               int tiles_total, int tiles_per_split, int n_co_t) {
+    constexpr int MT = TM / 64;                       // 32x32 tiles per wave per dimension
+    constexpr int NCH = TM / 32;                      // 32-channel chunks per operand
+    constexpr int CHB = 64 * PROW;                    // bytes per chunk (64 pixel rows)
+    constexpr int PPP = TM / 8;                       // 16-B pieces per pixel
+    constexpr int PXS = 256 / PPP;                    // pixels staged per pass
+    constexpr int KP = 64 / PXS;                      // passes
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * NCH * CHB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wci = wave >> 1, wco = wave & 1;
+    const int ci0 = (blockIdx.x / n_co_t) * TM, co0 = (blockIdx.x % n_co_t) * TM;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    int t_end = t_begin + tiles_per_split;
+    if (t_end > tiles_total) t_end = tiles_total;
+
+    const int sub = tid % PPP, prow = tid / PPP;
+    const int lds_off = (sub >> 2) * CHB + prow * PROW + (sub & 3) * 16;        // + k*PXS*PROW ; dy: + NCH*CHB
+    constexpr unsigned OOB = 0x7FFFFFFFu;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + ci0), 0, (int)(M * ldx * 2 - ci0 * 2 > 0x7FFFFFF0L ? 0x7FFFFFF0L : M * ldx * 2 - ci0 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + co0), 0, (int)(M * lddy * 2 - co0 * 2 > 0x7FFFFFF0L ? 0x7FFFFFF0L : M * lddy * 2 - co0 * 2), 0x00020000);
+
+    floatx16 acc[MT][MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    half8 xraw[KP], yraw[KP];
+    bool xval[KP];
+
+#define UMI_ISSUE1(tile_)                                                                                         \
+    do {                                                                                                         \
+        const long m0_ = (long)(tile_) * 64;                                                                     \
+        _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                         \
+            long m = m0_ + prow + k * PXS;                                                                       \
+            xval[k] = m < M;                                                                                     \
+            unsigned ox = xval[k] ? (unsigned)(m * ldx * 2 + sub * 16) : OOB;                                    \
+            unsigned oy = xval[k] ? (unsigned)(m * lddy * 2 + sub * 16) : OOB;                                   \
+            xraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, ox, 0, 0));           \
+            yraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(yrs, oy, 0, 0));           \
+        }                                                                                                        \
+    } while (0)
+
+    const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+    const int frag_lane = (8 * (g >> 1) + lq) * PROW + (16 * (g & 1) + 4 * lp) * 2;
+    const unsigned char* a_frag = smem + (wci * MT) * CHB + frag_lane;                  // + mt*CHB + ks*16*PROW
+    const unsigned char* b_frag = smem + NCH * CHB + (wco * MT) * CHB + frag_lane;      // + nt*CHB + ks*16*PROW
+
+    if (t_begin < t_end) UMI_ISSUE1(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        if (HAS_TX) {
+            int opaque = 0;
+            asm volatile("" : "+v"(opaque));
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = tx[ci0 + sub * 8 + j + opaque];
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+                if (xval[k]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xraw[k][j] = (half_t)umi_tx((float)xraw[k][j], t[j]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            *reinterpret_cast<half8*>(smem + lds_off + k * PXS * PROW) = xraw[k];
+            *reinterpret_cast<half8*>(smem + NCH * CHB + lds_off + k * PXS * PROW) = yraw[k];
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) UMI_ISSUE1(tile + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 af[MT], bf[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = tr_frag(a_frag + mt * CHB + ks * 16 * PROW);
+#pragma unroll
+            for (int nt = 0; nt < MT; ++nt) bf[nt] = tr_frag(b_frag + nt * CHB + ks * 16 * PROW);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef UMI_ISSUE1
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < MT; ++nt) {
+            const int co = co0 + (wco * MT + nt) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int ci = ci0 + (wci * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                part[((long)blockIdx.y * Ci + ci) * Co + co] = acc[mt][nt][r];
+            }
+        }
+}
+
+void plan1(long M, int Ci, int Co, int TM, int* tiles_total, int* splits, int* tps) {
+    *tiles_total = (int)((M + 63) / 64);
+    const long pairs = (long)(Ci / TM) * (Co / TM);
+    long want = (1024 + pairs - 1) / pairs;
+    const long slab = (long)Ci * Co * 4;
+    long cap = (64L << 20) / slab;
+    if (cap < 1) cap = 1;
+    if (pairs * cap < 512 && pairs < 512) cap = (512 + pairs - 1) / pairs;
+    if (want > cap) want = cap;
+    if (want > *tiles_total) want = *tiles_total;
+    if (want < 1) want = 1;
+    *tps = (int)((*tiles_total + want - 1) / want);
+    *splits = (*tiles_total + *tps - 1) / *tps;
+}
+
 }  // namespace
+
+bool umi_wgrad1x1_mfma_ok(long M, int Ci, int Co, int R, int S, int stride, int pad, int ldx, int lddy, int dtype, int flags,
+                          const void* txb) {
+    if (flags & UMI_CONV_FORCE_GENERIC) return false;
+    if (dtype != UMI_F16 || txb) return false;
+    if (R != 1 || S != 1 || stride != 1 || pad != 0) return false;
+    if (Ci % 64 || Co % 64 || ldx % 8 || lddy % 8) return false;
+    if (M * (long)(ldx > lddy ? ldx : lddy) * 2 >= 0x7FFFFFF0L) return false;     // 32-bit buffer offsets
+    return true;
+}
+static int wgrad1x1_tm(int Ci, int Co) { return (Ci % 128 == 0 && Co % 128 == 0) ? 128 : 64; }
+
+size_t umi_wgrad1x1_mfma_ws_bytes(long M, int Ci, int Co) {
+    int tt, splits, tps;
+    plan1(M, Ci, Co, wgrad1x1_tm(Ci, Co), &tt, &splits, &tps);
+    return (size_t)splits * Ci * Co * sizeof(float);
+}
+
+int umi_wgrad1x1_mfma(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
+                      long s_t, float out_scale, long M, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int TM = wgrad1x1_tm(Ci, Co);
+    int tt, splits, tps;
+    plan1(M, Ci, Co, TM, &tt, &splits, &tps);
+    if (ws_bytes < (size_t)splits * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
+    if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
+    const int n_co_t = Co / TM;
+    dim3 grid((Ci / TM) * n_co_t, splits), block(256);
+#define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t)
+    if (TM == 128) { if (txa) GO(128, true); else GO(128, false); }
+    else { if (txa) GO(64, true); else GO(64, false); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    umi_launch_wgrad_reduce((const float*)ws, splits, 1, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
 
 bool umi_wgradT_mfma_ok(int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int ldx,
                         int lddy, int dtype, int flags, const void* txa) {
