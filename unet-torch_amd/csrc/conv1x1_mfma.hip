@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     constexpr int KPX = P * 8 / 256;          // 8
     constexpr int KPW = BN * 8 / 256;         // 4 or 2
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    __shared__ float4 txbuf[2][CK];          // transform rows of the current / next K chunk, refilled two chunks ahead
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
@@ -106,13 +107,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     const int b_base = (wm * NT * 32 + lrow) * ROWB + lhalf * 16;         // + nt*32*ROWB + ks*32
     const int a_base = XB + (wn * 64 + lrow) * ROWB + lhalf * 16;         // + mt*32*ROWB + ks*32
 
+#define UMI_TXROW(cc_) (tx[(IN_S2D ? (cc_) % chunks_per_tap : (cc_)) * CK + tid])
+    float4 txr = make_float4(0.f, 1.f, 0.f, 0.f);
+    if (HAS_TX) {
+        if (tid < CK) {
+            txbuf[0][tid] = UMI_TXROW(0);
+            if (nchunks > 1) txbuf[1][tid] = UMI_TXROW(1);
+            if (nchunks > 2) txr = UMI_TXROW(2);
+        }
+        __syncthreads();
+    }
     UMI_ISSUE(0);
     for (int c = 0; c < nchunks; ++c) {
         if (HAS_TX) {
-            const int kc = IN_S2D ? c % chunks_per_tap : c;
             float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = tx[kc * CK + sub * 8 + j];
+            for (int j = 0; j < 8; ++j) t[j] = txbuf[c & 1][sub * 8 + j];
 #pragma unroll
             for (int k = 0; k < KPX; ++k)
                 if (xoff[k] >= 0) {
@@ -125,6 +135,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 #pragma unroll
         for (int k = 0; k < KPW; ++k) *reinterpret_cast<half8*>(smem + wl + k * 32 * ROWB) = wraw[k];
         __syncthreads();
+        if (HAS_TX && tid < CK && c + 2 < nchunks) {
+            txbuf[c & 1][tid] = txr;                  // all readers of this buffer are past the barrier above
+            if (c + 3 < nchunks) txr = UMI_TXROW(c + 3);
+        }
         if (c + 1 < nchunks) UMI_ISSUE(c + 1);
 #pragma unroll
         for (int ks = 0; ks < CK / 16; ++ks) {
@@ -142,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         __syncthreads();
     }
 #undef UMI_ISSUE
+#undef UMI_TXROW
 
     // ---- epilogue: (+bias) -> fp16 -> LDS tile [pixel][BN] -> 16-B stores (scattered per tap for OUT_UPS) -----
 #pragma unroll

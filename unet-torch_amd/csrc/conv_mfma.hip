@@ -28,6 +28,19 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifdef UMI_STAMP
+// diagnostic build only: per-wave cycle sums of the main-loop segments (never compiled into the shipped library)
+__device__ unsigned long long umi_stamp_buf[2048 * 8];
+#define UMI_T(var)                                                                        \
+    unsigned long long var;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0)
+extern "C" int umi_debug_read_stamps(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(umi_stamp_buf), sizeof(umi_stamp_buf));
+}
+#endif
+
 namespace {
 
 constexpr int HALO_W = 34;      // 32 + 2
@@ -58,12 +71,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     int tiles_y, int n_co) {
     using C = Cfg<TH, BN>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];
-    __shared__ float red[2][4][BN];
+    // consumer-transform rows of the current / next chunk (16 channels x float4), refilled two chunks ahead so the
+    // transform never waits on a global load (measured with in-kernel stamps: 8 dependent tx loads per chunk cost
+    // ~1,650 of the ~7,200 cycles of a main-loop iteration)
+    __shared__ float4 txbuf[2][16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wn = wave % C::WN, wm = wave / C::WN;
+#ifdef UMI_STAMP
+    UMI_T(t_start);
+#endif
 
     const int cb = blockIdx.x % n_co;
     const int pt = blockIdx.x / n_co;
@@ -109,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     half8 hraw[C::KPH], wraw[C::KPW];
+    float4 txr = make_float4(0.f, 1.f, 0.f, 0.f);
 #define UMI_ISSUE(c_)                                                                                              \
     do {                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < C::KPH; ++k)                                                        \
@@ -127,14 +147,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     // (Rotating the chunk order per workgroup to spread the weight reads over L2 channels was measured and is
     //  SLOWER: -12 % on 1024->1024; simultaneous readers of one panel share L2 lines.)
 #define UMI_CHUNK(i_) (i_)
+    if (HAS_TX) {
+        if (tid < 16) {
+            txbuf[0][tid] = tx[tid];
+            if (nchunks > 1) txbuf[1][tid] = tx[16 + tid];
+        }
+        __syncthreads();
+    }
     UMI_ISSUE(UMI_CHUNK(0));
+    if (HAS_TX && nchunks > 2 && tid < 16) txr = tx[2 * 16 + tid];
+#ifdef UMI_STAMP
+    unsigned long long seg[5] = {0, 0, 0, 0, 0};
+    UMI_T(t_loop);
+#endif
     for (int ci_ = 0; ci_ < nchunks; ++ci_) {
         const int c = UMI_CHUNK(ci_);
+#ifdef UMI_STAMP
+        UMI_T(t0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UMI_T(t0b);
+#endif
         // ---- registers -> (transform) -> LDS ----------------------------------------------------
         if (HAS_TX) {
             float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = tx[c * 16 + q * 8 + j];
+            for (int j = 0; j < 8; ++j) t[j] = txbuf[ci_ & 1][q * 8 + j];
 #pragma unroll
             for (int k = 0; k < C::KPH; ++k) {
                 if (hoff[k] != OOB) {
@@ -156,7 +193,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #pragma unroll
         for (int k = 0; k < C::KPW; ++k) asm volatile("" ::"v"(wraw[k]));
 #endif
+#ifdef UMI_STAMP
+        UMI_T(t1);
+#endif
         __syncthreads();
+#ifdef UMI_STAMP
+        UMI_T(t2);
+#endif
+        if (HAS_TX && tid < 16 && ci_ + 2 < nchunks) {
+            txbuf[ci_ & 1][tid] = txr;                        // every thread is past its reads of this buffer (barrier above)
+            if (ci_ + 3 < nchunks) txr = tx[(ci_ + 3) * 16 + tid];
+        }
         if (ci_ + 1 < nchunks) UMI_ISSUE(UMI_CHUNK(ci_ + 1));
 
         // ---- MFMA phase: 9 taps x (2 x 4) tiles -----------------------------------------------
@@ -181,8 +228,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             }
         }
 #endif
+#ifdef UMI_STAMP
+        UMI_T(t3);
+#endif
         __syncthreads();
+#ifdef UMI_STAMP
+        UMI_T(t4);
+        seg[0] += t0b - t0; seg[1] += t1 - t0b; seg[2] += t2 - t1; seg[3] += t3 - t2; seg[4] += t4 - t3;
+#endif
     }
+#ifdef UMI_STAMP
+    UMI_T(t_ep0);
+#endif
 
     // ---- epilogue: acc -> fp16 LDS tile [pixel][BN] ----------------------------------------------
 #pragma unroll
@@ -201,41 +258,71 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         }
     __syncthreads();
 
-    // coalesced 16-B stores of the tile
-    constexpr int PPR = BN / 8;                     // 16-B pieces per pixel row
-#pragma unroll 4
-    for (int i = tid; i < C::P * PPR; i += 256) {
-        int p = i / PPR, j = i - p * PPR;
-        int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
-        if (gy < H && gx < W) {
-            uint4 v = *reinterpret_cast<const uint4*>(smem + p * C::ERS + j * 16);
-            *reinterpret_cast<uint4*>(y + ((long)((long)n * H + gy) * W + gx) * ldy + c0 + j * 8) = v;
+    // coalesced 16-B stores of the tile.  piece i = tid + 256k -> pixel p = i / PPR, 16-B column j = i % PPR; with PPR a
+    // power of two p = p0 + k*PSTEP, so rows/cols advance by constants (no divisions in the loop).
+    constexpr int PPR = BN / 8;                     // 16-B pieces per pixel row (16 or 8)
+    constexpr int PSTEP = 256 / PPR;                // pixels advanced per k (16 or 32)
+    constexpr int NK = C::P / PSTEP;                // 16
+    const bool full_tile = (ty0 + TH <= H) && (tx0 + 32 <= W);
+    {
+        const int j = tid % PPR, p0 = tid / PPR;
+        half_t* ybase = y + ((long)((long)n * H + ty0) * W + tx0) * ldy + c0 + j * 8;
+        const unsigned char* sbase = smem + p0 * C::ERS + j * 16;
+#pragma unroll 8
+        for (int k = 0; k < NK; ++k) {
+            const int p = p0 + k * PSTEP;
+            const int row = p >> 5, col = p & 31;
+            if (full_tile || (ty0 + row < H && tx0 + col < W)) {
+                uint4 v = *reinterpret_cast<const uint4*>(sbase + k * PSTEP * C::ERS);
+                *reinterpret_cast<uint4*>(ybase + ((long)row * W + col) * ldy) = v;
+            }
         }
     }
 
     if (STATS) {
-        constexpr int SL = 256 / BN;               // pixel slices
-        const int col = tid % BN, sl = tid / BN;
-        float s = 0.f, s2 = 0.f;
-        for (int p = sl * (C::P / SL); p < (sl + 1) * (C::P / SL); ++p) {
-            int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
-            if (gy < H && gx < W) {
-                float v = (float)*reinterpret_cast<const half_t*>(smem + p * C::ERS + col * 2);
-                s += v;
-                s2 = fmaf(v, v, s2);
+        // column sums from the LDS tile, 8 channels (one 16-B read) per thread per pixel: thread = (col group, pixel slice)
+        constexpr int CG = BN / 8;                  // column groups (16 or 8)
+        constexpr int SL = 256 / CG;                // pixel slices (16 or 32)
+        constexpr int PPS = C::P / SL;              // pixels per slice (16)
+        const int cg = tid % CG, sl = tid / CG;
+        float s[8], s2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = s2[j] = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < PPS; ++k) {
+            const int p = sl * PPS + k;
+            if (full_tile || (ty0 + (p >> 5) < H && tx0 + (p & 31) < W)) {
+                half8 v = *reinterpret_cast<const half8*>(smem + p * C::ERS + cg * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; s2[j] = fmaf(f, f, s2[j]); }
             }
         }
-        red[0][sl][col] = s;
-        red[1][sl][col] = s2;
+        __syncthreads();                            // every thread is done with the tile: reuse it for the slice sums
+        float* rs = reinterpret_cast<float*>(smem);         // [2][SL][BN]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            rs[(0 * SL + sl) * BN + cg * 8 + j] = s[j];
+            rs[(1 * SL + sl) * BN + cg * 8 + j] = s2[j];
+        }
         __syncthreads();
         if (tid < 2 * BN) {
-            int which = tid / BN, cc = tid % BN;
+            const int which = tid / BN, cc = tid % BN;
             float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < SL; ++k) a += red[which][k][cc];
+#pragma unroll 8
+            for (int k = 0; k < SL; ++k) a += rs[(which * SL + k) * BN + cc];
             part[((long)pt * 2 + which) * Co + c0 + cc] = a;
         }
     }
+#ifdef UMI_STAMP
+    UMI_T(t_end);
+    if (lane == 0 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) umi_stamp_buf[(blockIdx.x * 4 + wave) * 8 + i] = seg[i];
+        umi_stamp_buf[(blockIdx.x * 4 + wave) * 8 + 5] = nchunks;
+        umi_stamp_buf[(blockIdx.x * 4 + wave) * 8 + 6] = t_loop - t_start;
+        umi_stamp_buf[(blockIdx.x * 4 + wave) * 8 + 7] = t_end - t_ep0;
+    }
+#endif
 }
 
 template <int TH, int BN>
