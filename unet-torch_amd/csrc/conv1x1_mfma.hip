@@ -126,8 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 #pragma unroll
             for (int k = 0; k < KPX; ++k)
                 if (xoff[k] >= 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) xraw[k][j] = (half_t)umi_tx((float)xraw[k][j], t[j]);
+                    xraw[k] = umi_tx8(xraw[k], t);
                 }
         }
 #pragma unroll

@@ -175,8 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #pragma unroll
             for (int k = 0; k < C::KPH; ++k) {
                 if (hoff[k] != OOB) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) hraw[k][j] = (half_t)umi_tx((float)hraw[k][j], t[j]);
+                    hraw[k] = umi_tx8(hraw[k], t);
                 }
             }
         }

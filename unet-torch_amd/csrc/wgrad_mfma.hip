@@ -132,8 +132,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
 #pragma unroll
             for (int k = 0; k < KPA; ++k)
                 if (avalid[k]) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) araw[k][j] = (half_t)umi_tx((float)araw[k][j], t[j]);
+                    araw[k] = umi_tx8(araw[k], t);
                 }
         }
 #pragma unroll
@@ -271,8 +270,7 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
 #pragma unroll
             for (int k = 0; k < KPY2; ++k)
                 if (yvalid[k]) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) yraw[k][j] = (half_t)umi_tx((float)yraw[k][j], t[j]);
+                    yraw[k] = umi_tx8(yraw[k], t);
                 }
         }
 #pragma unroll
@@ -414,8 +412,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
 #pragma unroll
             for (int k = 0; k < KP; ++k)
                 if (xval[k]) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) xraw[k][j] = (half_t)umi_tx((float)xraw[k][j], t[j]);
+                    xraw[k] = umi_tx8(xraw[k], t);
                 }
         }
 #pragma unroll
