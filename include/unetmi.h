@@ -137,9 +137,11 @@ int umi_wstd_bwd(const float* wstd, const float* rstd, const float* g, float* dw
 /* GroupNorm (+ optional residual add, + optional ReLU) on NHWC, y = [relu](gn(x) [+ res]) (resnet_skip.py:47-58,68-73).
  * mean/rstd: [N*G] saved for backward.  Backward: dx (and dres = masked dy when dres != NULL), dgamma/dbeta scaled by
  * out_scale; `y` is the forward OUTPUT (ReLU mask). */
+size_t umi_gn_fwd_ws_bytes(int N, long HW, int C);
 int umi_gn_fwd(const void* x, int ldx, const float* gamma, const float* beta, const void* res, int ldr, void* y, int ldy,
-               float* mean, float* rstd, int relu, int N, long HW, int C, int G, float eps, int dtype, umi_stream_t stream);
-size_t umi_gn_bwd_ws_bytes(int N, int C, int G);
+               float* mean, float* rstd, int relu, int N, long HW, int C, int G, float eps, int dtype,
+               void* ws, size_t ws_bytes, umi_stream_t stream);
+size_t umi_gn_bwd_ws_bytes(int N, long HW, int C, int G);
 int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                const float* rstd, const float* gamma, int relu, void* dx, int lddx, void* dres, int lddr,
                float* dgamma, float* dbeta, float out_scale, int N, long HW, int C, int G, int dtype,

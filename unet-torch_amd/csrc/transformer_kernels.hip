@@ -541,6 +541,13 @@ __global__ void bilinear2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __r
 }  // namespace
 
 void umi_launch_reduce_rows2(const float* ws, int rows, int C, float* out0, float* out1, float scale, hipStream_t s);
+// groupnorm_f16.hip
+int umi_gn_splits(long HW);
+bool umi_gn_stats_f16v(const void* x, int ldx, int N, long HW, int C, int G, float eps, float* mean, float* rstd, float* ws,
+                       hipStream_t s);
+bool umi_gn_bwd_reduce_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
+                            const float* rstd, const float* gamma, int relu, int N, long HW, int C, int G, float* gsum,
+                            float* part, float* ws, hipStream_t s);
 
 #define DT_SWITCH(dtype, CALL_F32, CALL_F16)             \
     if ((dtype) == UMI_F32) { CALL_F32; }                \
@@ -560,12 +567,20 @@ extern "C" int umi_wstd_bwd(const float* wstd, const float* rstd, const float* g
     return UMI_OK;
 }
 
+extern "C" size_t umi_gn_fwd_ws_bytes(int N, long HW, int C) { return (size_t)N * umi_gn_splits(HW) * 2 * C * sizeof(float); }
+
 extern "C" int umi_gn_fwd(const void* x, int ldx, const float* gamma, const float* beta, const void* res, int ldr, void* y,
                           int ldy, float* mean, float* rstd, int relu, int N, long HW, int C, int G, float eps, int dtype,
-                          umi_stream_t st) {
+                          void* ws, size_t ws_bytes, umi_stream_t st) {
     if (!x || !y || !gamma || !beta || !mean || !rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G) return UMI_ERR_BADARG;
     hipStream_t s = (hipStream_t)st;
     const int grid = grid_for((long)N * HW * C);
+    if (dtype == UMI_F16 && ws && ws_bytes >= umi_gn_fwd_ws_bytes(N, HW, C) &&
+        umi_gn_stats_f16v(x, ldx, N, HW, C, G, eps, mean, rstd, (float*)ws, s)) {
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd, gamma, beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C, G);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     DT_SWITCH(dtype,
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(N * G), dim3(256), 0, s, (const float*)x, ldx, HW, C, G, eps, mean, rstd);
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, mean, rstd, gamma, beta, (const float*)res, ldr, (float*)y, ldy, relu, N, HW, C, G),
@@ -575,18 +590,29 @@ extern "C" int umi_gn_fwd(const void* x, int ldx, const float* gamma, const floa
     return UMI_OK;
 }
 
-extern "C" size_t umi_gn_bwd_ws_bytes(int N, int C, int G) { return ((size_t)N * G * 2 + (size_t)N * 2 * C) * sizeof(float); }
+extern "C" size_t umi_gn_bwd_ws_bytes(int N, long HW, int C, int G) {
+    return ((size_t)N * G * 2 + (size_t)N * 2 * C + (size_t)N * umi_gn_splits(HW) * 2 * C) * sizeof(float);
+}
 
 extern "C" int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                           const float* rstd, const float* gamma, int relu, void* dx, int lddx, void* dres, int lddr,
                           float* dgamma, float* dbeta, float out_scale, int N, long HW, int C, int G, int dtype, void* ws,
                           size_t ws_bytes, umi_stream_t st) {
     if (!dy || !y || !x || !dx || !dgamma || !dbeta || !ws || C % G) return UMI_ERR_BADARG;
-    if (ws_bytes < umi_gn_bwd_ws_bytes(N, C, G)) return UMI_ERR_WORKSPACE;
+    if (ws_bytes < umi_gn_bwd_ws_bytes(N, HW, C, G)) return UMI_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)st;
     float* gsum = (float*)ws;
     float* part = gsum + (size_t)N * G * 2;
+    float* stage1 = part + (size_t)N * 2 * C;
     const int grid = grid_for((long)N * HW * C);
+    if (dtype == UMI_F16 && umi_gn_bwd_reduce_f16v(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, relu, N, HW, C, G, gsum, part,
+                                                    stage1, s)) {
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx, (half_t*)dres, lddr, N, HW, C, G);
+        UMI_LAUNCH_CHECK();
+        umi_launch_reduce_rows2(part, N, C, dgamma, dbeta, out_scale, s);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     DT_SWITCH(dtype,
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(N * G), dim3(256), 0, s, (const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, mean, rstd, gamma, relu, HW, C, G, gsum, part);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, lddy, (const float*)y, ldy, (const float*)x, ldx, mean, rstd, gamma, gsum, relu, (float*)dx, lddx, (float*)dres, lddr, N, HW, C, G),

@@ -34,8 +34,10 @@ def gn_fwd(x, gamma, beta, groups, eps, relu, res, y):
     mean = torch.empty(N * groups, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     ldr = _nhwc(res)[4] if res is not None else 0
+    ws = workspace(L.fn("umi_gn_fwd_ws_bytes")(N, H * W, C), x.device)
     L.check(L.fn("umi_gn_fwd")(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(res), ldr, y.data_ptr(), ldy,
-                               mean.data_ptr(), rstd.data_ptr(), int(relu), N, H * W, C, groups, eps, _dt(x), _stream()),
+                               mean.data_ptr(), rstd.data_ptr(), int(relu), N, H * W, C, groups, eps, _dt(x),
+                               ws.data_ptr(), ws.numel(), _stream()),
             "umi_gn_fwd")
     return mean, rstd
 
@@ -44,7 +46,7 @@ def gn_bwd(dy, y, x, mean, rstd, gamma, groups, relu, dx, dres, out_scale):
     N, H, W, C, ldx = _nhwc(x)
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty_like(dg)
-    ws = workspace(L.fn("umi_gn_bwd_ws_bytes")(N, C, groups), x.device)
+    ws = workspace(L.fn("umi_gn_bwd_ws_bytes")(N, H * W, C, groups), x.device)
     L.check(L.fn("umi_gn_bwd")(dy.data_ptr(), _nhwc(dy)[4], y.data_ptr(), _nhwc(y)[4], x.data_ptr(), ldx, mean.data_ptr(),
                                rstd.data_ptr(), gamma.data_ptr(), int(relu), dx.data_ptr(), _nhwc(dx)[4], _ptr(dres),
                                _nhwc(dres)[4] if dres is not None else 0, dg.data_ptr(), db.data_ptr(), out_scale, N, H * W,
