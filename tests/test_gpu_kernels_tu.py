@@ -96,7 +96,9 @@ def test_layer_norm_gelu_pool_bilinear_fp32():
     _close(dxb.permute(0, 3, 1, 2), act.grad, 2e-5)
 
 
-@pytest.mark.parametrize("dt,tol,N,heads,D", [(torch.float32, 2e-5, 50, 4, 16), (torch.float16, 3e-3, 196, 3, 64)])
+@pytest.mark.parametrize("dt,tol,N,heads,D", [(torch.float32, 2e-5, 50, 4, 16), (torch.float16, 3e-3, 196, 3, 64),
+                                                 (torch.float16, 3e-3, 301, 2, 64), (torch.float16, 3e-3, 17, 1, 64),
+                                                 (torch.float16, 3e-3, 40, 2, 32)])
 def test_attention_fwd_bwd(dt, tol, N, heads, D):
     lib, ops, T = _gpu()
     g = torch.Generator().manual_seed(3)

@@ -548,6 +548,13 @@ bool umi_gn_stats_f16v(const void* x, int ldx, int N, long HW, int C, int G, flo
 bool umi_gn_bwd_reduce_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                             const float* rstd, const float* gamma, int relu, int N, long HW, int C, int G, float* gsum,
                             float* part, float* ws, hipStream_t s);
+// attention_mfma.hip
+bool umi_attn_mfma_ok(int D, int ld, int ldo, int dtype, const void* a, const void* b, const void* c);
+int umi_attn_fwd_mfma(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse, int B, int N, int Hh,
+                      hipStream_t s);
+int umi_attn_bwd_mfma(const void* q, const void* k, const void* v, int ld, const void* o, const void* dO, int ldo,
+                      const float* lse, void* dq, void* dk, void* dv, int ldd, float* delta, int B, int N, int Hh,
+                      hipStream_t s);
 
 #define DT_SWITCH(dtype, CALL_F32, CALL_F16)             \
     if ((dtype) == UMI_F32) { CALL_F32; }                \
@@ -711,6 +718,8 @@ static int attn_fwd_t(const void* q, const void* k, const void* v, int ld, void*
 extern "C" int umi_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse, int B, int N,
                             int heads, int D, int dtype, umi_stream_t st) {
     if (!q || !k || !v || !o || !lse || B <= 0 || N <= 0 || heads <= 0) return UMI_ERR_BADARG;
+    if (umi_attn_mfma_ok(D, ld, ldo, dtype, q, k, v) && (((uintptr_t)o) & 15) == 0)
+        return umi_attn_fwd_mfma(q, k, v, ld, o, ldo, lse, B, N, heads, (hipStream_t)st);
     int rc;
     if (dtype == UMI_F32) rc = attn_fwd_t<float>(q, k, v, ld, o, ldo, lse, B, N, heads, D, (hipStream_t)st);
     else if (dtype == UMI_F16) rc = attn_fwd_t<half_t>(q, k, v, ld, o, ldo, lse, B, N, heads, D, (hipStream_t)st);
@@ -739,6 +748,9 @@ extern "C" int umi_attn_bwd(const void* q, const void* k, const void* v, int ld,
                             const float* lse, void* dq, void* dk, void* dv, int ldd, float* delta, int B, int N, int heads,
                             int D, int dtype, umi_stream_t st) {
     if (!q || !k || !v || !o || !dO || !lse || !dq || !dk || !dv || !delta) return UMI_ERR_BADARG;
+    if (umi_attn_mfma_ok(D, ld, ldo, dtype, q, k, v) && ldd % 8 == 0 &&
+        ((((uintptr_t)o) | ((uintptr_t)dO) | ((uintptr_t)dq) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 15) == 0)
+        return umi_attn_bwd_mfma(q, k, v, ld, o, dO, ldo, lse, dq, dk, dv, ldd, delta, B, N, heads, (hipStream_t)st);
     int rc;
     if (dtype == UMI_F32) rc = attn_bwd_t<float>(q, k, v, ld, o, dO, ldo, lse, dq, dk, dv, ldd, delta, B, N, heads, D, (hipStream_t)st);
     else if (dtype == UMI_F16) rc = attn_bwd_t<half_t>(q, k, v, ld, o, dO, ldo, lse, dq, dk, dv, ldd, delta, B, N, heads, D, (hipStream_t)st);
