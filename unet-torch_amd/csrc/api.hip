@@ -1,6 +1,8 @@
 // C-ABI dispatch layer of libunetmi: validates arguments and picks the MFMA fast path or the
 // generic kernel.  See include/unetmi.h for the contract of every entry point.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 // generic_kernels.hip
 int umi_conv_fwd_generic(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy,
@@ -84,6 +86,16 @@ extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int
     return UMI_OK;
 }
 
+// UMI_TRACE_GENERIC=1: report every conv that lands on the generic (non-MFMA) kernels -- a tuning aid, off by default
+static bool trace_generic() {
+    static const bool on = [] { const char* e = getenv("UMI_TRACE_GENERIC"); return e && e[0] == '1'; }();
+    return on;
+}
+#define UMI_TRACE(kind)                                                                                                  \
+    if (trace_generic())                                                                                                 \
+        fprintf(stderr, "[umi generic %s] N=%d H=%d W=%d Ci=%d Co=%d R=%d stride=%d pad=%d flags=%d\n", kind, N, H, W, Ci, Co, R, \
+                stride, pad, flags)
+
 extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy,
                             float* stat_part, int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
                             int Ho, int Wo, int off_h, int off_w, int out_H, int out_W, int in_dtype, int out_dtype,
@@ -96,6 +108,7 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
         if (flags & UMI_CONV_UPSAMPLE2) return UMI_ERR_BADARG;
         if (H != (Ho + 2 * pad - R) / stride + 1 || W != (Wo + 2 * pad - S) / stride + 1) return UMI_ERR_BADARG;
         if (out_H != Ho || out_W != Wo || off_h || off_w || stat_part) return UMI_ERR_BADARG;
+        UMI_TRACE("dgrad_strided");
         return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
                                     off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);
     }
@@ -123,6 +136,7 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
         return umi_head_fwd(x, ldx, tx, wp, bias, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
     if (!stat_part && umi_smallk_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias))
         return umi_smallk_fwd(x, ldx, wp, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
+    UMI_TRACE("fwd");
     return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
                                 off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);
 }
@@ -174,6 +188,7 @@ extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const voi
     if (umi_head_wgrad_ok(Ci, Co, R, S, stride, pad, ldx, dtype, flags, txb))
         return umi_head_wgrad(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, (long)N * H * W, Ci, Co, ws,
                               ws_bytes, (hipStream_t)stream);
+    UMI_TRACE("wgrad");
     return umi_conv_wgrad_generic(x, ldx, txa, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S,
                                   stride, pad, Ho, Wo, dtype, ws, ws_bytes, (hipStream_t)stream);
 }

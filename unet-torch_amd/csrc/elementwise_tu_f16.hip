@@ -1,0 +1,301 @@
+// 16-byte vectorised fp16 variants of the TransUNet elementwise / normalisation kernels (thread = 8 channels of one row).
+// Arithmetic is the same fp32 expression per element as the scalar kernels in transformer_kernels.hip (the dropout
+// stream is keyed by the same element index), so either path gives the same values; these exist because the scalar
+// `i % C, i / C` form reaches only ~20 % of HBM bandwidth.  Every launcher returns false when the shape or alignment
+// does not qualify and the caller falls back to the scalar kernel.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+inline int grid8(long vecs) {
+    long g = (vecs + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float u) {
+    return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+}
+__device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {
+    unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ew8_kernel(const half_t* __restrict__ x, int ldx, const half_t* __restrict__ g, int ldg,
+                                                  half_t* __restrict__ y, int ldy, long M, int C8, long bcast_rows) {
+    const long total = M * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long r = i / C8;
+        half8 xv = *reinterpret_cast<const half8*>(x + r * ldx + c), gv, o;
+        if (MODE == 1 || MODE == 2) gv = *reinterpret_cast<const half8*>(g + r * ldg + c);
+        if (MODE == 3) gv = *reinterpret_cast<const half8*>(g + (r % bcast_rows) * ldg + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)xv[j], v;
+            if (MODE == 0) v = gelu_f(f);
+            else if (MODE == 1) v = (float)gv[j] * gelu_df(f);
+            else v = f + (float)gv[j];
+            o[j] = (half_t)v;
+        }
+        *reinterpret_cast<half8*>(y + r * ldy + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout8_kernel(const half_t* __restrict__ x, int ldx, half_t* __restrict__ y, int ldy,
+                                                       unsigned char* __restrict__ mask, int bwd, float p, unsigned seed,
+                                                       long M, int C8) {
+    const long total = M * C8;
+    const float scale = 1.f / (1.f - p);
+    const int C = C8 * 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long r = i / C8;
+        const long e0 = r * C + c;                                       // element index of the scalar kernel
+        half8 xv = *reinterpret_cast<const half8*>(x + r * ldx + c), o;
+        unsigned long long mk = 0;
+        if (bwd) mk = *reinterpret_cast<const unsigned long long*>(mask + e0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned k;
+            if (bwd) k = (unsigned)(mk >> (8 * j)) & 0xFFu;
+            else {
+                const long e = e0 + j;
+                float u = (hash32((unsigned)e, seed ^ (unsigned)(e >> 32)) >> 8) * (1.f / 16777216.f);
+                k = u >= p;
+                mk |= (unsigned long long)k << (8 * j);
+            }
+            o[j] = (half_t)(k ? (float)xv[j] * scale : 0.f);
+        }
+        if (!bwd) *reinterpret_cast<unsigned long long*>(mask + e0) = mk;
+        *reinterpret_cast<half8*>(y + r * ldy + c) = o;
+    }
+}
+
+// LayerNorm backward: one wave per row, lane owns K4 groups of 4 channels (C <= 4*64*K4; C = 768 -> K4 = 3); dgamma/dbeta
+// stay in registers across the rows of a wave and leave as one partial row per workgroup (fixed order => deterministic)
+constexpr int LNV_ROWS = 16;       // rows per backward workgroup (4 per wave)
+template <int K4>
+__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const half_t* __restrict__ dy, int lddy, const half_t* __restrict__ x,
+                                                        int ldx, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, half_t* __restrict__ dx, int lddx,
+                                                        float* __restrict__ part, long M, int C) {
+    __shared__ float red[3][2][K4 * 256];                       // waves 1..3 -> wave 0
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float gm[K4][4], dg[K4][4], db[K4][4];
+#pragma unroll
+    for (int k = 0; k < K4; ++k) {
+        const int c = (lane + 64 * k) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gm[k][j] = c < C ? gamma[c + j] : 0.f; dg[k][j] = 0.f; db[k][j] = 0.f; }
+    }
+    const float invC = 1.f / C;
+    const long r0 = (long)blockIdx.x * LNV_ROWS;
+    for (int rr = wave; rr < LNV_ROWS; rr += 4) {
+        const long row = r0 + rr;
+        if (row >= M) break;
+        const float m = mean[row], r = rstd[row];
+        float d[K4][4], xh[K4][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < K4; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            half4 hd = {0, 0, 0, 0}, hx = {0, 0, 0, 0};
+            if (c < C) {
+                hd = *reinterpret_cast<const half4*>(dy + row * lddy + c);
+                hx = *reinterpret_cast<const half4*>(x + row * ldx + c);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[k][j] = (float)hd[j];
+                xh[k][j] = c < C ? ((float)hx[j] - m) * r : 0.f;
+                const float g = d[k][j] * gm[k][j];
+                s1 += g;
+                s2 = fmaf(g, xh[k][j], s2);
+            }
+        }
+        s1 = wave_sum(s1) * invC;
+        s2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int k = 0; k < K4; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (half_t)(r * (d[k][j] * gm[k][j] - s1 - xh[k][j] * s2));
+                dg[k][j] = fmaf(d[k][j], xh[k][j], dg[k][j]);
+                db[k][j] += d[k][j];
+            }
+            if (c < C) *reinterpret_cast<half4*>(dx + row * lddx + c) = o;
+        }
+    }
+    if (wave) {
+#pragma unroll
+        for (int k = 0; k < K4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[wave - 1][0][(k * 4 + j) * 64 + lane] = dg[k][j];
+                red[wave - 1][1][(k * 4 + j) * 64 + lane] = db[k][j];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < K4; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c >= C) continue;
+            float ap[4], bp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sa = dg[k][j], sb = db[k][j];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) { sa += red[w][0][(k * 4 + j) * 64 + lane]; sb += red[w][1][(k * 4 + j) * 64 + lane]; }
+                ap[j] = sa;
+                bp[j] = sb;
+            }
+            *reinterpret_cast<float4*>(part + ((long)blockIdx.x * 2 + 0) * C + c) = make_float4(ap[0], ap[1], ap[2], ap[3]);
+            *reinterpret_cast<float4*>(part + ((long)blockIdx.x * 2 + 1) * C + c) = make_float4(bp[0], bp[1], bp[2], bp[3]);
+        }
+    }
+}
+
+// GroupNorm apply / backward apply, 8 channels per thread (all 8 in one group: Cg % 8 == 0)
+__global__ __launch_bounds__(256) void gn_apply8_kernel(const half_t* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const half_t* __restrict__ res, int ldr,
+                                                        half_t* __restrict__ y, int ldy, int relu, int N, long HW, int C8,
+                                                        int G, int Cg) {
+    const long total = (long)N * HW * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long p = i / C8;
+        const int n = (int)(p / HW);
+        const int sg = n * G + c / Cg;
+        const float m = mean[sg], r = rstd[sg];
+        half8 xv = *reinterpret_cast<const half8*>(x + p * ldx + c), rv, o;
+        if (res) rv = *reinterpret_cast<const half8*>(res + p * ldr + c);
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = ((float)xv[j] - m) * r * gg[j] + bb[j];
+            if (res) v += (float)rv[j];
+            if (relu) v = fmaxf(v, 0.f);
+            o[j] = (half_t)v;
+        }
+        *reinterpret_cast<half8*>(y + p * ldy + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply8_kernel(const half_t* __restrict__ dy, int lddy, const half_t* __restrict__ y,
+                                                            int ldy, const half_t* __restrict__ x, int ldx,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ gsum,
+                                                            int relu, half_t* __restrict__ dx, int lddx, half_t* __restrict__ dres,
+                                                            int lddr, int N, long HW, int C8, int G, int Cg) {
+    const float invm = 1.f / (float)(HW * Cg);
+    const long total = (long)N * HW * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long p = i / C8;
+        const int n = (int)(p / HW);
+        const int sg = n * G + c / Cg;
+        const float m = mean[sg], r = rstd[sg], q1 = gsum[sg * 2 + 0] * invm, q2 = gsum[sg * 2 + 1] * invm;
+        half8 gv = *reinterpret_cast<const half8*>(dy + p * lddy + c);
+        half8 xv = *reinterpret_cast<const half8*>(x + p * ldx + c), yv, o, dz8;
+        if (relu) yv = *reinterpret_cast<const half8*>(y + p * ldy + c);
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dz = (float)gv[j];
+            if (relu && !((float)yv[j] > 0.f)) dz = 0.f;
+            const float xh = ((float)xv[j] - m) * r;
+            o[j] = (half_t)(r * (dz * gg[j] - q1 - xh * q2));
+            dz8[j] = (half_t)dz;
+        }
+        *reinterpret_cast<half8*>(dx + p * lddx + c) = o;
+        if (dres) *reinterpret_cast<half8*>(dres + p * lddr + c) = dz8;
+    }
+}
+
+}  // namespace
+
+bool umi_ew_f16v(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C, long bcast_rows,
+                 hipStream_t s) {
+    if (C % 8 || ldx % 8 || ldy % 8 || (mode && ldg % 8) || !al16(x) || !al16(y) || (mode && !al16(g))) return false;
+    const int C8 = C / 8;
+    const int grid = grid8(M * C8);
+    const half_t* xp = (const half_t*)x;
+    const half_t* gp = (const half_t*)g;
+    half_t* yp = (half_t*)y;
+    if (mode == 0) hipLaunchKernelGGL(ew8_kernel<0>, dim3(grid), dim3(256), 0, s, xp, ldx, gp, ldg, yp, ldy, M, C8, bcast_rows);
+    else if (mode == 1) hipLaunchKernelGGL(ew8_kernel<1>, dim3(grid), dim3(256), 0, s, xp, ldx, gp, ldg, yp, ldy, M, C8, bcast_rows);
+    else if (mode == 2) hipLaunchKernelGGL(ew8_kernel<2>, dim3(grid), dim3(256), 0, s, xp, ldx, gp, ldg, yp, ldy, M, C8, bcast_rows);
+    else hipLaunchKernelGGL(ew8_kernel<3>, dim3(grid), dim3(256), 0, s, xp, ldx, gp, ldg, yp, ldy, M, C8, bcast_rows);
+    return true;
+}
+
+bool umi_dropout_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
+                      hipStream_t s) {
+    if (C % 8 || ldx % 8 || ldy % 8 || !al16(x) || !al16(y) || (((uintptr_t)mask) & 7)) return false;
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(dropout8_kernel, dim3(grid8(M * C8)), dim3(256), 0, s, (const half_t*)x, ldx, (half_t*)y, ldy,
+                       (unsigned char*)mask, backward, p, seed, M, C8);
+    return true;
+}
+
+int umi_ln_bwd_rows_f16v() { return LNV_ROWS; }
+
+// part rows = ceil(M / LNV_ROWS), layout [rows][2][C] as the scalar kernel's
+bool umi_ln_bwd_f16v(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
+                     void* dx, int lddx, float* part, long M, int C, hipStream_t s) {
+    if (C % 4 || C > 1024 || lddy % 4 || ldx % 4 || lddx % 4 || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 7) ||
+        (((uintptr_t)part) & 15))
+        return false;
+    const int rows = (int)((M + LNV_ROWS - 1) / LNV_ROWS);
+    const int K4 = (C / 4 + 63) / 64;
+#define GO(K)                                                                                                            \
+    hipLaunchKernelGGL(ln_bwd_v4_kernel<K>, dim3(rows), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)x, ldx, gamma, \
+                       mean, rstd, (half_t*)dx, lddx, part, M, C)
+    if (K4 == 1) GO(1); else if (K4 == 2) GO(2); else if (K4 == 3) GO(3); else GO(4);
+#undef GO
+    return true;
+}
+
+bool umi_gn_apply_f16v(const void* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const void* res, int ldr, void* y, int ldy, int relu, int N, long HW, int C, int G, hipStream_t s) {
+    if (C % G || (C / G) % 8 || ldx % 8 || ldy % 8 || (res && ldr % 8) || !al16(x) || !al16(y) || (res && !al16(res)) ||
+        !al16(gamma) || !al16(beta))
+        return false;
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(gn_apply8_kernel, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd, gamma,
+                       beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C8, G, C / G);
+    return true;
+}
+
+bool umi_gn_bwd_apply_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
+                           const float* rstd, const float* gamma, const float* gsum, int relu, void* dx, int lddx, void* dres,
+                           int lddr, int N, long HW, int C, int G, hipStream_t s) {
+    if (C % G || (C / G) % 8 || lddy % 8 || ldy % 8 || ldx % 8 || lddx % 8 || (dres && lddr % 8) || !al16(dy) || !al16(y) ||
+        !al16(x) || !al16(dx) || (dres && !al16(dres)) || !al16(gamma))
+        return false;
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(gn_bwd_apply8_kernel, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)dy, lddy,
+                       (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx,
+                       (half_t*)dres, lddr, N, HW, C8, G, C / G);
+    return true;
+}

@@ -548,6 +548,19 @@ bool umi_gn_stats_f16v(const void* x, int ldx, int N, long HW, int C, int G, flo
 bool umi_gn_bwd_reduce_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                             const float* rstd, const float* gamma, int relu, int N, long HW, int C, int G, float* gsum,
                             float* part, float* ws, hipStream_t s);
+// elementwise_tu_f16.hip
+bool umi_ew_f16v(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C, long bcast_rows,
+                 hipStream_t s);
+bool umi_dropout_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
+                      hipStream_t s);
+int umi_ln_bwd_rows_f16v();
+bool umi_ln_bwd_f16v(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
+                     void* dx, int lddx, float* part, long M, int C, hipStream_t s);
+bool umi_gn_apply_f16v(const void* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       const void* res, int ldr, void* y, int ldy, int relu, int N, long HW, int C, int G, hipStream_t s);
+bool umi_gn_bwd_apply_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
+                           const float* rstd, const float* gamma, const float* gsum, int relu, void* dx, int lddx, void* dres,
+                           int lddr, int N, long HW, int C, int G, hipStream_t s);
 // attention_mfma.hip
 bool umi_attn_mfma_ok(int D, int ld, int ldo, int dtype, const void* a, const void* b, const void* c);
 int umi_attn_fwd_mfma(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse, int B, int N, int Hh,
@@ -584,6 +597,10 @@ extern "C" int umi_gn_fwd(const void* x, int ldx, const float* gamma, const floa
     const int grid = grid_for((long)N * HW * C);
     if (dtype == UMI_F16 && ws && ws_bytes >= umi_gn_fwd_ws_bytes(N, HW, C) &&
         umi_gn_stats_f16v(x, ldx, N, HW, C, G, eps, mean, rstd, (float*)ws, s)) {
+        if (umi_gn_apply_f16v(x, ldx, mean, rstd, gamma, beta, res, ldr, y, ldy, relu, N, HW, C, G, s)) {
+            UMI_LAUNCH_CHECK();
+            return UMI_OK;
+        }
         hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd, gamma, beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C, G);
         UMI_LAUNCH_CHECK();
         return UMI_OK;
@@ -614,6 +631,7 @@ extern "C" int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, cons
     const int grid = grid_for((long)N * HW * C);
     if (dtype == UMI_F16 && umi_gn_bwd_reduce_f16v(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, relu, N, HW, C, G, gsum, part,
                                                     stage1, s)) {
+        if (!umi_gn_bwd_apply_f16v(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, gsum, relu, dx, lddx, dres, lddr, N, HW, C, G, s))
         hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx, (half_t*)dres, lddr, N, HW, C, G);
         UMI_LAUNCH_CHECK();
         umi_launch_reduce_rows2(part, N, C, dgamma, dbeta, out_scale, s);
@@ -663,16 +681,26 @@ extern "C" int umi_ln_fwd(const void* x, int ldx, const float* gamma, const floa
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }
-extern "C" size_t umi_ln_bwd_ws_bytes(long M, int C) { return (size_t)((M + LN_RPB - 1) / LN_RPB) * 2 * C * sizeof(float); }
+extern "C" size_t umi_ln_bwd_ws_bytes(long M, int C) {
+    const int rpb = umi_ln_bwd_rows_f16v() < LN_RPB ? umi_ln_bwd_rows_f16v() : LN_RPB;      // the path with more partial rows
+    return (size_t)((M + rpb - 1) / rpb) * 2 * C * sizeof(float);
+}
 extern "C" int umi_ln_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean,
                           const float* rstd, void* dx, int lddx, float* dgamma, float* dbeta, float out_scale, long M, int C,
                           int dtype, void* ws, size_t ws_bytes, umi_stream_t st) {
     if (!dy || !x || !dx || !dgamma || !dbeta || !ws) return UMI_ERR_BADARG;
     if (ws_bytes < umi_ln_bwd_ws_bytes(M, C)) return UMI_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)st;
+    if (dtype == UMI_F16 && umi_ln_bwd_f16v(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (float*)ws, M, C, s)) {
+        UMI_LAUNCH_CHECK();
+        const int vrows = (int)((M + umi_ln_bwd_rows_f16v() - 1) / umi_ln_bwd_rows_f16v());
+        umi_launch_reduce_rows2((const float*)ws, vrows, C, dgamma, dbeta, out_scale, s);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     if ((size_t)8 * C * sizeof(float) > 64 * 1024) return UMI_ERR_UNSUPPORTED;
     const int rows = (int)((M + LN_RPB - 1) / LN_RPB);
     const size_t smem = (size_t)8 * C * sizeof(float);
-    hipStream_t s = (hipStream_t)st;
     DT_SWITCH(dtype,
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(rows), dim3(256), smem, s, (const float*)dy, lddy, (const float*)x, ldx, gamma, mean, rstd, (float*)dx, lddx, (float*)ws, M, C),
         hipLaunchKernelGGL(ln_bwd_kernel<half_t>, dim3(rows), dim3(256), smem, s, (const half_t*)dy, lddy, (const half_t*)x, ldx, gamma, mean, rstd, (half_t*)dx, lddx, (float*)ws, M, C))
@@ -685,6 +713,10 @@ extern "C" int umi_ln_bwd(const void* dy, int lddy, const void* x, int ldx, cons
 extern "C" int umi_elementwise(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C,
                                long bcast_rows, int dtype, umi_stream_t st) {
     if (!x || !y || M <= 0 || C <= 0 || mode < 0 || mode > 3 || (mode && !g)) return UMI_ERR_BADARG;
+    if (dtype == UMI_F16 && umi_ew_f16v(mode, x, ldx, g, ldg, y, ldy, M, C, bcast_rows > 0 ? bcast_rows : 1, (hipStream_t)st)) {
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     const int grid = grid_for(M * C);
     DT_SWITCH(dtype,
         hipLaunchKernelGGL(ew_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)st, mode, (const float*)x, ldx, (const float*)g, ldg, (float*)y, ldy, M, C, bcast_rows > 0 ? bcast_rows : 1),
@@ -696,6 +728,10 @@ extern "C" int umi_elementwise(int mode, const void* x, int ldx, const void* g, 
 extern "C" int umi_dropout(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M,
                            int C, int dtype, umi_stream_t st) {
     if (!x || !y || !mask || p < 0.f || p >= 1.f) return UMI_ERR_BADARG;
+    if (dtype == UMI_F16 && umi_dropout_f16v(x, ldx, y, ldy, mask, backward, p, seed, M, C, (hipStream_t)st)) {
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     const int grid = grid_for(M * C);
     DT_SWITCH(dtype,
         hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const float*)x, ldx, (float*)y, ldy, (unsigned char*)mask, backward, p, seed, M, C),
