@@ -168,3 +168,38 @@ def test_wgrad1x1_mfma_and_colsum(shape):
     gp = torch.empty(20000, device=DEV)
     ops.colsum(wide.to(DEV), gp, 1.0)
     _close(gp, wide[0, 0].sum(0), 1e-5)
+
+
+@pytest.mark.parametrize("R,stride,pad,Ci,Co,H,W", [(3, 2, 1, 64, 128, 11, 13), (1, 2, 0, 128, 64, 11, 13), (3, 2, 1, 128, 128, 55, 55),
+                                                   (7, 2, 3, 64, 64, 20, 17), (3, 3, 0, 64, 64, 14, 16)])
+def test_strided_conv_mfma_gather_fp16(R, stride, pad, Ci, Co, H, W):
+    """Strided convs (resnet_skip.py:52-60) on the tap-gather MFMA kernels: forward, data gradient, weight gradient, with a
+    consumer-side transform on the input (zero padding applies AFTER the transform)."""
+    lib, ops, T = _gpu()
+    from umi.graph_tu import TUTape
+    g = torch.Generator().manual_seed(11)
+    N = 2
+    x = torch.randn(N, Ci, H, W, generator=g).half()
+    w = (torch.randn(Co, Ci, R, R, generator=g) * (1.0 / math.sqrt(Ci * R * R)))
+    wq = w.half().float()
+    scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    tx = torch.stack([torch.zeros(Ci), scale, shift, torch.zeros(Ci)], 1).contiguous()          # relu(x*scale + shift)
+    xa = torch.relu(x.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).half().float().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    y_ref = F.conv2d(xa, wr, None, stride, pad)
+    gy = torch.randn(y_ref.shape, generator=g).half()
+    y_ref.backward(gy.float())
+    Ho, Wo = y_ref.shape[2:]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.empty(N, Ho, Wo, Co, device=DEV, dtype=torch.float16)
+    lay, _ = ops.conv_plan(xd, y, R, R, stride, pad)
+    assert lay == 1, "expected the MFMA (k8) path for this shape"
+    ops.conv_fwd(xd, tx.to(DEV), lambda l: ops.pack_conv_fwd(w.to(DEV), torch.float16, k8=bool(l)), None, y, R, R, stride, pad)
+    _close(y.permute(0, 3, 1, 2), y_ref, 3e-3)
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = torch.empty(N, H, W, Ci, device=DEV, dtype=torch.float16)
+    TUTape._strided_dgrad(gyd, lambda l: T.pack_conv_dgrad_strided(w.to(DEV), torch.float16, k8=bool(l)), dx, R, R, stride, pad)
+    _close(dx.permute(0, 3, 1, 2), xa.grad, 4e-3)
+    dW = torch.empty(Co, Ci, R, R, device=DEV)
+    ops.conv_wgrad(xd, tx.to(DEV), gyd, None, dW, Ci * R * R, R * R, 1, 1.0, R, R, stride, pad)
+    _close(dW, wr.grad, 4e-3)

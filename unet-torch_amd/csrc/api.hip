@@ -57,6 +57,12 @@ size_t umi_wgradT_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co);
 int umi_wgradT_mfma(const void* x, int ldx, const void* dy, int lddy, const void* txb, float* dW, long s_co, long s_ci,
                     long s_t, float out_scale, int N, int Ho, int Wo, int Ci, int Co, void* ws, size_t ws_bytes,
                     hipStream_t s);
+bool umi_wgrad_gather_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int ldx,
+                              int lddy, int dtype, int flags, const void* txb);
+size_t umi_wgrad_gather_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co, int R, int S);
+int umi_wgrad_gather_mfma(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
+                          long s_t, float out_scale, int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
+                          int Ho, int Wo, void* ws, size_t ws_bytes, hipStream_t s);
 bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
                           int ldx, int lddy, int dtype, int flags, const void* txb);
 size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co);
@@ -74,11 +80,12 @@ extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int
     const bool ups = flags & UMI_CONV_UPSAMPLE2;
     const int Ho = ups ? H : (H + 2 * pad - R) / stride + 1, Wo = ups ? W : (W + 2 * pad - S) / stride + 1;
     static const float one = 1.f;
-    const bool mfma = umi_conv3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, in_dtype, out_dtype,
-                                          flags, has_bias ? &one : nullptr);
+    const bool dgs = flags & UMI_CONV_DGRAD_STRIDED;      // only the tap-gather MFMA kernel or the generic one take these
+    const bool mfma = !dgs && umi_conv3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, in_dtype, out_dtype,
+                                                  flags, has_bias ? &one : nullptr);
     const bool mfma1 = !mfma && umi_conv1x1_mfma_ok(Ci, Co, R, S, stride, pad, ldx, ldy, in_dtype, out_dtype, flags);
     if (layout) *layout = (mfma || mfma1) ? 1 : 0;
-    const bool stem = !mfma && !mfma1 &&
+    const bool stem = !mfma && !mfma1 && !dgs &&
                       umi_stem_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, has_bias ? &one : nullptr);
     if (stat_rows)
         *stat_rows = mfma ? umi_conv3x3_mfma_stat_rows(N, H, W, Co)
@@ -108,6 +115,11 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
         if (flags & UMI_CONV_UPSAMPLE2) return UMI_ERR_BADARG;
         if (H != (Ho + 2 * pad - R) / stride + 1 || W != (Wo + 2 * pad - S) / stride + 1) return UMI_ERR_BADARG;
         if (out_H != Ho || out_W != Wo || off_h || off_w || stat_part) return UMI_ERR_BADARG;
+        if (umi_conv1x1_mfma_ok(Ci, Co, R, S, stride, pad, ldx, ldy, in_dtype, out_dtype, flags)) {
+            if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wp) & 15) return UMI_ERR_BADARG;
+            return umi_conv1x1_mfma(x, ldx, tx, wp, bias, y, ldy, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, 0, 0, Ho, Wo,
+                                    flags, (hipStream_t)stream);
+        }
         UMI_TRACE("dgrad_strided");
         return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
                                     off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);
@@ -156,6 +168,10 @@ extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co,
         size_t m = umi_wgradT_mfma_ws_bytes(N, Ho, Wo, Ci, Co);
         if (m > g) g = m;
     }
+    if (dtype == UMI_F16 && Ci % 64 == 0 && Co % 64 == 0 && R * S <= 49 && !(flags & UMI_CONV_FORCE_GENERIC)) {
+        size_t m = umi_wgrad_gather_mfma_ws_bytes(N, Ho, Wo, Ci, Co, R, S);
+        if (m > g) g = m;
+    }
     if (umi_stem_wgrad_ok(Ci, Co, R, S, 1, 1, 8, dtype, flags, nullptr)) {
         size_t m = umi_stem_wgrad_ws_bytes(N, Ho, Wo, Ci, Co);
         if (m > g) g = m;
@@ -182,6 +198,9 @@ extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const voi
     if (umi_wgradT_mfma_ok(H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, lddy, dtype, flags, txa))
         return umi_wgradT_mfma(x, ldx, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, Ho, Wo, Ci, Co, ws, ws_bytes,
                                (hipStream_t)stream);
+    if (umi_wgrad_gather_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, lddy, dtype, flags, txb))
+        return umi_wgrad_gather_mfma(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S, stride, pad,
+                                     Ho, Wo, ws, ws_bytes, (hipStream_t)stream);
     if (umi_stem_wgrad_ok(Ci, Co, R, S, stride, pad, lddy, dtype, flags, txb))
         return umi_stem_wgrad(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes,
                               (hipStream_t)stream);

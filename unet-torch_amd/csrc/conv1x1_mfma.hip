@@ -2,8 +2,12 @@
 //   * plain 1x1 conv                                   y[p][co]        = sum_k  tx(x[p][k]) * w[k][co] (+ bias)
 //   * ConvTranspose2d(k=2,s=2) forward  (OUT_UPS)      y[2p+t][co]     = sum_k  tx(x[p][k]) * w_t[k][co] + bias
 //       = a 1x1 conv with 4*Cout outputs whose epilogue scatters channel block t to sub-pixel t
-//   * its data gradient                 (IN_S2D)       dx[p][ci]       = sum_t sum_k dy[2p+t][k] * w_t[k][ci]
+//   * its data gradient                 (GATHER)       dx[p][ci]       = sum_t sum_k dy[2p+t][k] * w_t[k][ci]
 //       = a 1x1 conv whose K axis is the space-to-depth gather of the 4 sub-pixels
+//   * any other R x S conv with stride / padding (GATHER): K axis = R*S taps x Ci, source pixel of tap (ty,tx) =
+//       (stride*y + ty - pad, stride*x + tx - pad), zero outside the image (TransUNet's stride-2 3x3 and 1x1 convs,
+//       resnet_skip.py:52-56,60) and the data gradient of a strided conv (UMI_CONV_DGRAD_STRIDED, "fractional" gather:
+//       source = ((y + pad - ty) / stride, (x + pad - tx) / stride) where that is integral)
 // (reference Model.py:56-57,67 and the autograd of it; TransUNet's 1x1 convs / patch embedding reuse it).
 //
 // D[co][pixel] += W[co][k] * X[k][pixel] with v_mfma_f32_32x32x16_f16 (A = weights, B = pixels), same
@@ -25,15 +29,16 @@ constexpr int ROWB = 144;     // LDS row bytes (64 halfs + 16 B pad)
 
 struct Geo {                  // geometry of the (optionally strided) source / destination tensors
     int h, w;                 // the pixel grid the GEMM's M index runs over (N*h*w pixels)
-    int Hs, Ws, soy, sox;     // source tensor dims (+ window offset) ; for IN_S2D source pixel = (2y+dy+soy, 2x+dx+sox)
+    int Hs, Ws, soy, sox;     // source tensor dims (+ window offset) ; GATHER: source pixel = (s*y+ty-pad+soy, s*x+tx-pad+sox)
     int Hd, Wd, doy, dox;     // destination dims (+ offset)          ; for OUT_UPS dest pixel = (2y+dy+doy, 2x+dx+dox)
+    int S, stride, pad, frac; // GATHER: taps per row, stride, padding; frac = data gradient of a strided conv
 };
 
-template <int BN, bool IN_S2D, bool OUT_UPS, bool HAS_TX>
+template <int BN, bool GATHER, bool OUT_UPS, bool HAS_TX>
 __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     const float* __restrict__ bias, half_t* __restrict__ y, int ldy, long M, int Kc /*channels per tap of the source*/,
-    int Nc /*channels per tap of the destination*/, int n_co, Geo geo) {
+    int Nc /*channels per tap of the destination*/, int n_co, int ntaps, Geo geo) {
     constexpr int WN = BN / 64, WM = 4 / WN, NT = P / (32 * WM);
     constexpr int XB = P * ROWB, WB = BN * ROWB;
     constexpr int ERS = BN * 2 + 16, EB = P * ERS;
@@ -51,17 +56,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     const int sub = tid & 7;
 
     // ---- staging plan --------------------------------------------------------------------------------
-    long xoff[KPX];                           // element offset of this thread's pixel k in the source (tap 0), or -1
+    long xoff[KPX];                           // plain: element offset of this thread's pixel k in the source, or -1
+    int nH[KPX], by[KPX], bx[KPX];            // GATHER: image row base n*Hs and the tap-0 source coordinate of pixel k
+    bool xv[KPX];                             // this pixel's piece of the chunk in flight is inside the image
 #pragma unroll
     for (int k = 0; k < KPX; ++k) {
         long m = m0 + (tid >> 3) + 32 * k;
+        xoff[k] = -1;
+        nH[k] = 0; by[k] = -(1 << 28); bx[k] = 0;          // far outside: every tap of a pixel beyond M is "padding"
+        xv[k] = m < M;
         if (m < M) {
             int n = (int)(m / ((long)geo.h * geo.w));
             int r = (int)(m - (long)n * geo.h * geo.w);
             int yy = r / geo.w, xx = r - yy * geo.w;
-            if (IN_S2D) { yy = 2 * yy + geo.soy; xx = 2 * xx + geo.sox; }
-            xoff[k] = ((long)((long)n * geo.Hs + yy) * geo.Ws + xx) * ldx + sub * 8;
-        } else xoff[k] = -1;
+            if (GATHER) {
+                nH[k] = n * geo.Hs;
+                by[k] = geo.frac ? yy + geo.pad : yy * geo.stride - geo.pad + geo.soy;
+                bx[k] = geo.frac ? xx + geo.pad : xx * geo.stride - geo.pad + geo.sox;
+            } else xoff[k] = ((long)((long)n * geo.Hs + yy) * geo.Ws + xx) * ldx + sub * 8;
+        }
     }
     long woff[KPW];                           // element offset of weight row k (chunk 0)
 #pragma unroll
@@ -69,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         int cop = c0 + (tid >> 3) + 32 * k;   // output channel index in [0, taps_out * Nc)
         int tap = OUT_UPS ? cop / Nc : 0;
         int co = cop - tap * Nc;
-        // OUT_UPS : wp8 = [4][Kc/8][Nc][8]  (tap of the OUTPUT);   IN_S2D: wp8 = [4][Kc/8][Nc][8] (tap of the INPUT)
+        // OUT_UPS : wp8 = [4][Kc/8][Nc][8]  (tap of the OUTPUT);   GATHER: wp8 = [R*S][Kc/8][Nc][8] (tap of the INPUT)
         woff[k] = ((long)((long)tap * (Kc >> 3) + sub) * Nc + co) * 8;
     }
     const int xl = (tid >> 3) * ROWB + sub * 16;            // + k*32*ROWB
@@ -89,16 +102,33 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
 
     const int chunks_per_tap = Kc / CK;
-    const int nchunks = IN_S2D ? 4 * chunks_per_tap : chunks_per_tap;
+    const int nchunks = GATHER ? ntaps * chunks_per_tap : chunks_per_tap;
 #define UMI_ISSUE(c_)                                                                                              \
     do {                                                                                                          \
         const int cc = (c_);                                                                                      \
-        const int tap_in = IN_S2D ? cc / chunks_per_tap : 0;                                                      \
+        const int tap_in = GATHER ? cc / chunks_per_tap : 0;                                                      \
         const int kc = cc - tap_in * chunks_per_tap;                                                              \
-        const long xadd = (long)kc * CK + (IN_S2D ? ((long)(tap_in >> 1) * geo.Ws + (tap_in & 1)) * ldx : 0);     \
+        const long xadd = (long)kc * CK;                                                                          \
         const long wadd = ((long)tap_in * (Kc >> 3) + kc * 8) * Nc * 8;                                           \
-        _Pragma("unroll") for (int k = 0; k < KPX; ++k)                                                           \
-            xraw[k] = xoff[k] >= 0 ? *reinterpret_cast<const half8*>(x + xoff[k] + xadd) : zero8;                 \
+        if (GATHER) {                                                                                             \
+            const int ty = tap_in / geo.S, tx_ = tap_in - ty * geo.S;                                             \
+            _Pragma("unroll") for (int k = 0; k < KPX; ++k) {                                                     \
+                int ys = by[k] + ty, xs = bx[k] + tx_;                                                            \
+                bool ok = true;                                                                                   \
+                if (geo.frac) {                                                                                   \
+                    ys = by[k] - ty; xs = bx[k] - tx_;                                                            \
+                    ok = ys >= 0 && xs >= 0 && ys % geo.stride == 0 && xs % geo.stride == 0;                      \
+                    ys /= geo.stride; xs /= geo.stride;                                                           \
+                }                                                                                                 \
+                ok = ok && ys >= 0 && ys < geo.Hs && xs >= 0 && xs < geo.Ws;                                       \
+                xv[k] = ok;                                                                                       \
+                xraw[k] = ok ? *reinterpret_cast<const half8*>(x + ((long)(nH[k] + ys) * geo.Ws + xs) * ldx + sub * 8 + xadd) \
+                             : zero8;                                                                             \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < KPX; ++k)                                                       \
+                xraw[k] = xoff[k] >= 0 ? *reinterpret_cast<const half8*>(x + xoff[k] + xadd) : zero8;             \
+        }                                                                                                         \
         _Pragma("unroll") for (int k = 0; k < KPW; ++k)                                                           \
             wraw[k] = *reinterpret_cast<const half8*>(wp8 + woff[k] + wadd);                                      \
     } while (0)
@@ -107,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     const int b_base = (wm * NT * 32 + lrow) * ROWB + lhalf * 16;         // + nt*32*ROWB + ks*32
     const int a_base = XB + (wn * 64 + lrow) * ROWB + lhalf * 16;         // + mt*32*ROWB + ks*32
 
-#define UMI_TXROW(cc_) (tx[(IN_S2D ? (cc_) % chunks_per_tap : (cc_)) * CK + tid])
+#define UMI_TXROW(cc_) (tx[(GATHER ? (cc_) % chunks_per_tap : (cc_)) * CK + tid])
     float4 txr = make_float4(0.f, 1.f, 0.f, 0.f);
     if (HAS_TX) {
         if (tid < CK) {
@@ -125,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
             for (int j = 0; j < 8; ++j) t[j] = txbuf[c & 1][sub * 8 + j];
 #pragma unroll
             for (int k = 0; k < KPX; ++k)
-                if (xoff[k] >= 0) {
+                if (xv[k]) {
                     xraw[k] = umi_tx8(xraw[k], t);
                 }
         }
@@ -203,13 +233,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 
 template <int BN>
 int launch(bool s2d, bool ups, const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y,
-           int ldy, long M, int Kc, int Nc, int Ntot, Geo geo, hipStream_t s) {
+           int ldy, long M, int Kc, int Nc, int Ntot, int ntaps, Geo geo, hipStream_t s) {
     const int n_co = Ntot / BN;
     const long nblk = ((M + P - 1) / P) * n_co;
     dim3 grid((unsigned)nblk), block(256);
 #define GO(S2D, UPS, HT)                                                                                          \
     hipLaunchKernelGGL((conv1x1_mfma_kernel<BN, S2D, UPS, HT>), grid, block, 0, s, (const half_t*)x, ldx,         \
-                       (const float4*)tx, (const half_t*)wp8, bias, (half_t*)y, ldy, M, Kc, Nc, n_co, geo)
+                       (const float4*)tx, (const half_t*)wp8, bias, (half_t*)y, ldy, M, Kc, Nc, n_co, ntaps, geo)
     if (s2d) { if (tx) GO(true, false, true); else GO(true, false, false); }
     else if (ups) { if (tx) GO(false, true, true); else GO(false, true, false); }
     else { if (tx) GO(false, false, true); else GO(false, false, false); }
@@ -220,11 +250,14 @@ int launch(bool s2d, bool ups, const void* x, int ldx, const void* tx, const voi
 
 }  // namespace
 
-// mode: 0 = plain 1x1, 1 = ConvT(2,2) forward (UMI_CONV_UPSAMPLE2), 2 = stride-2 2x2 conv (ConvT data gradient)
+// mode: 0 = plain 1x1, 1 = ConvT(2,2) forward (UMI_CONV_UPSAMPLE2), 2 = tap gather (ConvT data gradient = stride-2 2x2 conv,
+// strided R x S convs, data gradient of a strided conv)
 int umi_conv1x1_mode(int R, int S, int stride, int pad, int flags) {
     if (flags & UMI_CONV_UPSAMPLE2) return (R == 2 && S == 2) ? 1 : -1;
+    if (R * S > 49 || pad < 0 || pad >= 1 << 20) return -1;
+    if (flags & UMI_CONV_DGRAD_STRIDED) return stride >= 1 ? 2 : -1;
     if (R == 1 && S == 1 && stride == 1 && pad == 0) return 0;
-    if (R == 2 && S == 2 && stride == 2 && pad == 0) return 2;
+    if (stride >= 2) return 2;
     return -1;
 }
 
@@ -244,19 +277,20 @@ int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, co
     const int mode = umi_conv1x1_mode(R, S, stride, pad, flags);
     Geo geo;
     long M;
-    int Kc = Ci, Nc = Co, Ntot = Co;
+    int Kc = Ci, Nc = Co, Ntot = Co, ntaps = 1;
     if (mode == 0) {
-        geo = Geo{H, W, H, W, 0, 0, H, W, 0, 0};
+        geo = Geo{H, W, H, W, 0, 0, H, W, 0, 0, 1, 1, 0, 0};
         M = (long)N * H * W;
     } else if (mode == 1) {            // input grid HxW -> output (out_H x out_W), 4 taps of Co channels each
-        geo = Geo{H, W, H, W, 0, 0, out_H, out_W, off_h, off_w};
+        geo = Geo{H, W, H, W, 0, 0, out_H, out_W, off_h, off_w, 1, 1, 0, 0};
         M = (long)N * H * W;
         Ntot = 4 * Co;
-    } else {                           // source is HxW, GEMM grid = Ho x Wo, K = 4 taps x Ci
-        geo = Geo{Ho, Wo, H, W, 0, 0, Ho, Wo, 0, 0};
+    } else {                           // source is HxW, GEMM grid = Ho x Wo, K = R*S taps x Ci
+        geo = Geo{Ho, Wo, H, W, 0, 0, Ho, Wo, 0, 0, S, stride, pad, (flags & UMI_CONV_DGRAD_STRIDED) ? 1 : 0};
         M = (long)N * Ho * Wo;
+        ntaps = R * S;
     }
     if (Ntot % 128 == 0)
-        return launch<128>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, geo, s);
-    return launch<64>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, geo, s);
+        return launch<128>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s);
+    return launch<64>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s);
 }

@@ -342,12 +342,16 @@ void plan(int N, int H, int W, int Ci, int Co, int* tiles_x, int* tiles_y, int* 
 // (TransUNet: QKV/out/MLP linears vit_seg_modeling.py:58-62,100-101, patch embedding, bottleneck 1x1 convs).
 // Pixels are linear rows (dense NHWC), K tile = 64 rows.  Block tile TM x TM channels, 2 x 2 waves, each wave
 // (TM/2)^2 = MT x MT accumulator tiles; both operands by transposing LDS reads.
-template <int TM, bool HAS_TX>
+// GATHER: weight gradient of any R x S conv with stride / padding (TransUNet's stride-2 convs, resnet_skip.py:52-60):
+// blockIdx.z = tap, dy rows stay linear, the x row of dy pixel (n, ho, wo) is (n, s*ho + ty - pad, s*wo + tx - pad),
+// zero outside the image:  dW[tap][ci][co] = sum_p tx(x[gather(p, tap)])[ci] * dy[p][co].
+struct WGeo { int Ho, Wo, H, W, S, stride, pad; };
+template <int TM, bool HAS_TX, bool GATHER>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __restrict__ x, int ldx,
                                                                const float4* __restrict__ tx,
                                                                const half_t* __restrict__ dy, int lddy,
                                                                float* __restrict__ part, long M, int Ci, int Co,
-                                                               int tiles_total, int tiles_per_split, int n_co_t) {
+                                                               int tiles_total, int tiles_per_split, int n_co_t, WGeo geo) {
     constexpr int MT = TM / 64;                       // 32x32 tiles per wave per dimension
     constexpr int NCH = TM / 32;                      // 32-channel chunks per operand
     constexpr int CHB = 64 * PROW;                    // bytes per chunk (64 pixel rows)
@@ -370,7 +374,9 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
     const int sub = tid % PPP, prow = tid / PPP;
     const int lds_off = (sub >> 2) * CHB + prow * PROW + (sub & 3) * 16;        // + k*PXS*PROW ; dy: + NCH*CHB
     constexpr unsigned OOB = 0x7FFFFFFFu;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + ci0), 0, (int)(M * ldx * 2 - ci0 * 2 > 0x7FFFFFF0L ? 0x7FFFFFF0L : M * ldx * 2 - ci0 * 2), 0x00020000);
+    const long xrows = GATHER ? (M / ((long)geo.Ho * geo.Wo)) * geo.H * geo.W : M;       // pixel rows of the x tensor
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + ci0), 0, (int)(xrows * ldx * 2 - ci0 * 2 > 0x7FFFFFF0L ? 0x7FFFFFF0L : xrows * ldx * 2 - ci0 * 2), 0x00020000);
+    const int tap_y = GATHER ? (int)blockIdx.z / geo.S : 0, tap_x = GATHER ? (int)blockIdx.z - tap_y * geo.S : 0;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + co0), 0, (int)(M * lddy * 2 - co0 * 2 > 0x7FFFFFF0L ? 0x7FFFFFF0L : M * lddy * 2 - co0 * 2), 0x00020000);
 
     floatx16 acc[MT][MT];
@@ -389,8 +395,17 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
         _Pragma("unroll") for (int k = 0; k < KP; ++k) {                                                         \
             long m = m0_ + prow + k * PXS;                                                                       \
             xval[k] = m < M;                                                                                     \
-            unsigned ox = xval[k] ? (unsigned)(m * ldx * 2 + sub * 16) : OOB;                                    \
             unsigned oy = xval[k] ? (unsigned)(m * lddy * 2 + sub * 16) : OOB;                                   \
+            long mx = m;                                                                                         \
+            if (GATHER && xval[k]) {                                                                             \
+                const int hw = geo.Ho * geo.Wo;                                                                  \
+                const int n = (int)(m / hw), r = (int)(m - (long)n * hw);                                        \
+                const int ho = r / geo.Wo, wo = r - ho * geo.Wo;                                                 \
+                const int ys = ho * geo.stride + tap_y - geo.pad, xs = wo * geo.stride + tap_x - geo.pad;        \
+                xval[k] = ys >= 0 && ys < geo.H && xs >= 0 && xs < geo.W;                                        \
+                mx = ((long)n * geo.H + ys) * geo.W + xs;                                                        \
+            }                                                                                                    \
+            unsigned ox = xval[k] ? (unsigned)(mx * ldx * 2 + sub * 16) : OOB;                                   \
             xraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, ox, 0, 0));           \
             yraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(yrs, oy, 0, 0));           \
         }                                                                                                        \
@@ -446,16 +461,16 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int ci = ci0 + (wci * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                part[((long)blockIdx.y * Ci + ci) * Co + co] = acc[mt][nt][r];
+                part[(((long)blockIdx.y * gridDim.z + blockIdx.z) * Ci + ci) * Co + co] = acc[mt][nt][r];
             }
         }
 }
 
-void plan1(long M, int Ci, int Co, int TM, int* tiles_total, int* splits, int* tps) {
+void plan1(long M, int Ci, int Co, int TM, int* tiles_total, int* splits, int* tps, int taps = 1) {
     *tiles_total = (int)((M + 63) / 64);
-    const long pairs = (long)(Ci / TM) * (Co / TM);
+    const long pairs = (long)(Ci / TM) * (Co / TM) * taps;
     long want = (1024 + pairs - 1) / pairs;
-    const long slab = (long)Ci * Co * 4;
+    const long slab = (long)taps * Ci * Co * 4;
     long cap = (64L << 20) / slab;
     if (cap < 1) cap = 1;
     if (pairs * cap < 512 && pairs < 512) cap = (512 + pairs - 1) / pairs;
@@ -494,12 +509,53 @@ int umi_wgrad1x1_mfma(const void* x, int ldx, const void* txa, const void* dy, i
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
     const int n_co_t = Co / TM;
     dim3 grid((Ci / TM) * n_co_t, splits), block(256);
-#define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t)
+    const WGeo geo{1, 1, 1, 1, 1, 1, 0};
+#define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_, false>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t, geo)
     if (TM == 128) { if (txa) GO(128, true); else GO(128, false); }
     else { if (txa) GO(64, true); else GO(64, false); }
 #undef GO
     UMI_LAUNCH_CHECK();
     umi_launch_wgrad_reduce((const float*)ws, splits, 1, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// ---- tap-gather weight gradient (strided / padded R x S convs) ----------------------------------------------------------
+bool umi_wgrad_gather_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int ldx,
+                              int lddy, int dtype, int flags, const void* txb) {
+    if (flags & UMI_CONV_FORCE_GENERIC) return false;
+    if (dtype != UMI_F16 || txb) return false;
+    if (R * S > 49 || stride < 1 || pad < 0) return false;
+    if (Ho != (H + 2 * pad - R) / stride + 1 || Wo != (W + 2 * pad - S) / stride + 1) return false;
+    if (Ci % 64 || Co % 64 || ldx % 8 || lddy % 8) return false;
+    if ((long)N * Ho * Wo * lddy * 2 >= 0x7FFFFFF0L || (long)N * H * W * ldx * 2 >= 0x7FFFFFF0L) return false;
+    return true;
+}
+
+size_t umi_wgrad_gather_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co, int R, int S) {
+    int tt, splits, tps;
+    plan1((long)N * Ho * Wo, Ci, Co, wgrad1x1_tm(Ci, Co), &tt, &splits, &tps, R * S);
+    return (size_t)splits * R * S * Ci * Co * sizeof(float);
+}
+
+int umi_wgrad_gather_mfma(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
+                          long s_t, float out_scale, int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
+                          int Ho, int Wo, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int TM = wgrad1x1_tm(Ci, Co), taps = R * S;
+    const long M = (long)N * Ho * Wo;
+    int tt, splits, tps;
+    plan1(M, Ci, Co, TM, &tt, &splits, &tps, taps);
+    if (ws_bytes < (size_t)splits * taps * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
+    if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
+    const int n_co_t = Co / TM;
+    dim3 grid((Ci / TM) * n_co_t, splits, taps), block(256);
+    const WGeo geo{Ho, Wo, H, W, S, stride, pad};
+#define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_, true>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t, geo)
+    if (TM == 128) { if (txa) GO(128, true); else GO(128, false); }
+    else { if (txa) GO(64, true); else GO(64, false); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    umi_launch_wgrad_reduce((const float*)ws, splits, taps, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }

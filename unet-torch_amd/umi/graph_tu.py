@@ -52,16 +52,24 @@ class TUTape(Tape):
                         ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(ws, self.dtype, k8=bool(lay)), None, dx,
                                      R, S, 1, R - 1 - pad)
                     else:
-                        wpd = ops_tu.pack_conv_dgrad_strided(ws, self.dtype)
-                        self._strided_dgrad(o.grad, wpd, dx, R, S, stride, pad)
+                        self._strided_dgrad(o.grad, lambda lay: ops_tu.pack_conv_dgrad_strided(ws, self.dtype, k8=bool(lay)),
+                                            dx, R, S, stride, pad)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o
 
     @staticmethod
     def _strided_dgrad(dy, wpd, dx, R, S, stride, pad):
+        import ctypes
         N, Hd, Wd, Cd, lddy = ops._nhwc(dy)
         _, Hx, Wx, Cx, lddx = ops._nhwc(dx)
+        lay = ctypes.c_int(0)
+        L.check(L.fn("umi_conv_fwd_plan")(N, Hd, Wd, Cd, Cx, R, S, stride, pad, lddy, lddx, ops._dt(dy), ops._dt(dx),
+                                          L.CONV_DGRAD_STRIDED, 0, ctypes.addressof(lay), None), "umi_conv_fwd_plan")
+        if callable(wpd):
+            wpd = wpd(lay.value)
+        elif lay.value != 0:
+            raise ValueError("this data gradient takes the MFMA path: pass a callable so the weights get the k8 packing")
         L.check(L.fn("umi_conv_fwd")(dy.data_ptr(), lddy, None, wpd.data_ptr(), None, dx.data_ptr(), lddx, None,
                                      N, Hd, Wd, Cd, Cx, R, S, stride, pad, Hx, Wx, 0, 0, Hx, Wx, ops._dt(dy), ops._dt(dx),
                                      L.CONV_DGRAD_STRIDED | L.CONV_UPSAMPLE2 * 0, ops._stream()), "umi_conv_fwd(dgrad strided)")
