@@ -39,6 +39,9 @@ CASES = [  # N, H, W, Ci, Co, ldx_extra, ldy_extra, use_tx
     (2, 9, 33, 16, 192, 16, 64, True),     # channel-slice views (ld > C), 3 co-blocks of 64
     (1, 40, 32, 128, 256, 0, 128, False),  # no transform (dgrad-style), output into a concat half
     (3, 7, 5, 48, 64, 16, 0, True),        # image smaller than one tile
+    (2, 20, 45, 64, 16, 0, 0, True),       # Co = 16: partial output-channel tile (TransUNet decoder tail)
+    (2, 19, 33, 16, 16, 0, 16, True),      # Ci = Co = 16 into a channel slice
+    (1, 16, 40, 32, 200, 0, 0, False),     # 128 + 72 output channels
 ]
 
 
@@ -99,7 +102,8 @@ def test_conv3x3_mfma_dgrad_matches_autograd():
     assert (dx.float().cpu() - ref).abs().max().item() < 3e-3 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("shape", [(2, 20, 45, 32, 64), (1, 16, 64, 64, 128), (2, 9, 33, 16, 192), (1, 12, 12, 128, 64)])
+@pytest.mark.parametrize("shape", [(2, 20, 45, 32, 64), (1, 16, 64, 64, 128), (2, 9, 33, 16, 192), (1, 12, 12, 128, 64),
+                                   (2, 20, 45, 64, 16), (2, 19, 33, 16, 16), (1, 10, 40, 72, 24)])
 def test_wgrad_fast_path_vs_reference_and_generic(shape):
     lib, ops = _gpu()
     N, H, W, Ci, Co = shape

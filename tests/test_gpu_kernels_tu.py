@@ -203,3 +203,53 @@ def test_strided_conv_mfma_gather_fp16(R, stride, pad, Ci, Co, H, W):
     dW = torch.empty(Co, Ci, R, R, device=DEV)
     ops.conv_wgrad(xd, tx.to(DEV), gyd, None, dW, Ci * R * R, R * R, 1, 1.0, R, R, stride, pad)
     _close(dW, wr.grad, 4e-3)
+
+
+def test_root_conv_and_seg_head_narrow_kernels():
+    """ResNetV2 root (3 -> 64, 7x7 / s2 / p3, resnet_skip.py:120) and SegmentationHead (16 -> n_classes, 3x3 / p1, fp32 logits
+    + bias, vit_seg_modeling.py:317-323): forward and weight gradient, fast kernels vs torch and vs the generic kernels."""
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(21)
+    # root
+    N, H, W, Co = 2, 37, 41, 64
+    x = torch.randn(N, 3, H, W, generator=g).half()
+    w = torch.randn(Co, 3, 7, 7, generator=g) * 0.1
+    wr = w.half().float().clone().requires_grad_(True)
+    y_ref = F.conv2d(x.float(), wr, None, 2, 3)
+    gy = torch.randn(y_ref.shape, generator=g).half()
+    y_ref.backward(gy.float())
+    Ho, Wo = y_ref.shape[2:]
+    xd = torch.empty(N, H, W, 3, dtype=torch.float16, device=DEV)
+    xd.copy_(x.permute(0, 2, 3, 1))
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    for flags in (0, lib.CONV_FORCE_GENERIC):
+        y = torch.empty(N, Ho, Wo, Co, device=DEV, dtype=torch.float16)
+        ops.conv_fwd(xd, None, lambda l: ops.pack_conv_fwd(w.to(DEV), torch.float16, k8=bool(l)), None, y, 7, 7, 2, 3, flags=flags)
+        _close(y.permute(0, 3, 1, 2), y_ref, 3e-3)
+        dW = torch.empty(Co, 3, 7, 7, device=DEV)
+        ops.conv_wgrad(xd, None, gyd, None, dW, 3 * 49, 49, 1, 1.0, 7, 7, 2, 3, flags=flags)
+        _close(dW, wr.grad, 3e-3)
+    # segmentation head
+    N, H, W, Ci = 2, 21, 19, 16
+    for ncls in (2, 4):
+        x = torch.randn(N, Ci, H, W, generator=g).half()
+        scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+        tx = torch.stack([torch.zeros(Ci), scale, shift, torch.zeros(Ci)], 1).contiguous()
+        xa = torch.relu(x.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        w = torch.randn(ncls, Ci, 3, 3, generator=g) * 0.2
+        b = torch.randn(ncls, generator=g)
+        wr = w.half().float().clone().requires_grad_(True)
+        y_ref = F.conv2d(xa, wr, b, 1, 1)
+        gl = torch.randn(y_ref.shape, generator=g).half()
+        y_ref.backward(gl.float())
+        xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        gld = torch.empty(N, H, W, ncls, dtype=torch.float16, device=DEV)
+        gld.copy_(gl.permute(0, 2, 3, 1))
+        for flags in (0, lib.CONV_FORCE_GENERIC):
+            y = torch.empty(N, H, W, ncls, device=DEV, dtype=torch.float32)
+            ops.conv_fwd(xd, tx.to(DEV), lambda l: ops.pack_conv_fwd(w.to(DEV), torch.float16, k8=bool(l)), b.to(DEV), y, 3, 3, 1, 1,
+                         flags=flags)
+            _close(y.permute(0, 3, 1, 2), y_ref, 2e-3)
+            dW = torch.empty(ncls, Ci, 3, 3, device=DEV)
+            ops.conv_wgrad(xd, tx.to(DEV), gld, None, dW, Ci * 9, 9, 1, 1.0, 3, 3, 1, 1, flags=flags)
+            _close(dW, wr.grad, 3e-3)

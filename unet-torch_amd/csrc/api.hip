@@ -57,6 +57,23 @@ size_t umi_wgradT_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co);
 int umi_wgradT_mfma(const void* x, int ldx, const void* dy, int lddy, const void* txb, float* dW, long s_co, long s_ci,
                     long s_t, float out_scale, int N, int Ho, int Wo, int Ci, int Co, void* ws, size_t ws_bytes,
                     hipStream_t s);
+// narrow_convs.hip
+bool umi_root_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldy, int in_dtype, int out_dtype, int flags,
+                     const void* tx, const float* bias);
+int umi_root_fwd(const void* x, int ldx, const void* wp, void* y, int ldy, int N, int H, int W, int Ho, int Wo, int Co,
+                 hipStream_t s);
+bool umi_root_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int lddy, int dtype, int flags, const void* txa,
+                       const void* txb);
+size_t umi_root_wgrad_ws_bytes(int N, int Ho, int Wo, int Co);
+int umi_root_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dW, long s_co, long s_ci, long s_t, float out_scale,
+                   int N, int H, int W, int Ho, int Wo, int Co, void* ws, size_t ws_bytes, hipStream_t s);
+bool umi_head3_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int in_dtype, int out_dtype, int flags);
+int umi_head3_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy, int N, int H,
+                  int W, int Ci, int Co, hipStream_t s);
+bool umi_head3_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int dtype, int flags, const void* txb);
+size_t umi_head3_wgrad_ws_bytes(long P, int Ci, int Co);
+int umi_head3_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci, long s_t,
+                    float out_scale, int N, int H, int W, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s);
 bool umi_wgrad_gather_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int ldx,
                               int lddy, int dtype, int flags, const void* txb);
 size_t umi_wgrad_gather_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co, int R, int S);
@@ -148,6 +165,10 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
         return umi_head_fwd(x, ldx, tx, wp, bias, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
     if (!stat_part && umi_smallk_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias))
         return umi_smallk_fwd(x, ldx, wp, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
+    if (!stat_part && umi_root_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias))
+        return umi_root_fwd(x, ldx, wp, y, ldy, N, H, W, Ho, Wo, Co, (hipStream_t)stream);
+    if (!stat_part && umi_head3_fwd_ok(Ci, Co, R, S, stride, pad, ldx, in_dtype, out_dtype, flags))
+        return umi_head3_fwd(x, ldx, tx, wp, bias, y, ldy, N, H, W, Ci, Co, (hipStream_t)stream);
     UMI_TRACE("fwd");
     return umi_conv_fwd_generic(x, ldx, tx, wp, bias, y, ldy, stat_part, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
                                 off_h, off_w, out_H, out_W, in_dtype, out_dtype, flags, (hipStream_t)stream);
@@ -180,6 +201,14 @@ extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co,
         size_t m = umi_head_wgrad_ws_bytes((long)N * Ho * Wo, Ci, Co);
         if (m > g) g = m;
     }
+    if (umi_root_wgrad_ok(Ci, Co, R, S, 2, 3, 8, dtype, flags, nullptr, nullptr)) {
+        size_t m = umi_root_wgrad_ws_bytes(N, Ho, Wo, Co);
+        if (m > g) g = m;
+    }
+    if (umi_head3_wgrad_ok(Ci, Co, R, S, 1, 1, 8, dtype, flags, nullptr)) {
+        size_t m = umi_head3_wgrad_ws_bytes((long)N * Ho * Wo, Ci, Co);
+        if (m > g) g = m;
+    }
     return g;
 }
 
@@ -207,6 +236,12 @@ extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const voi
     if (umi_head_wgrad_ok(Ci, Co, R, S, stride, pad, ldx, dtype, flags, txb))
         return umi_head_wgrad(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, (long)N * H * W, Ci, Co, ws,
                               ws_bytes, (hipStream_t)stream);
+    if (umi_root_wgrad_ok(Ci, Co, R, S, stride, pad, lddy, dtype, flags, txa, txb))
+        return umi_root_wgrad(x, ldx, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ho, Wo, Co, ws, ws_bytes,
+                              (hipStream_t)stream);
+    if (umi_head3_wgrad_ok(Ci, Co, R, S, stride, pad, ldx, dtype, flags, txb))
+        return umi_head3_wgrad(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes,
+                               (hipStream_t)stream);
     UMI_TRACE("wgrad");
     return umi_conv_wgrad_generic(x, ldx, txa, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S,
                                   stride, pad, Ho, Wo, dtype, ws, ws_bytes, (hipStream_t)stream);

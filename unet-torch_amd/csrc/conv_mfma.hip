@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const int rem = pt - n * tiles_x * tiles_y;
     const int ty0 = (rem / tiles_x) * TH, tx0 = (rem % tiles_x) * 32;
     const int c0 = cb * BN;
+    const int cvalid = Co - c0 < BN ? Co - c0 : BN;   // output channels of this tile that exist (Co % 8 == 0, e.g. Co = 16)
     const int q = tid & 1;                         // which 8-channel half of the 16-channel chunk this thread stages
 
     // ---- per-thread staging plan (fixed across chunks) ------------------------------------------
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     // weight piece k: row rc = (tid>>1) + 128k of the [9*BN] rows -> tap = k*(128/BN) + (tid>>1)/BN
     constexpr int TSTEP = 128 / BN;
     const int tap0 = (tid >> 1) / BN, wcol = (tid >> 1) % BN;
+    const bool wok = wcol < cvalid;                // weight rows past Co read as zeros
     const int Ci8 = Ci >> 3;
     const unsigned wbase = (unsigned)(((tap0 * Ci8 + q) * Co + wcol) * 16);
     const unsigned wstep = (unsigned)(TSTEP * Ci8 * Co * 16);   // bytes per k step
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             hraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[k], (c_) * 32, 0)); \
         _Pragma("unroll") for (int k = 0; k < C::KPW; ++k)                                                        \
             wraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                            \
-                wrs, (tap0 + k * TSTEP < 9) ? wbase + k * wstep : OOB, (c_) * 2 * Co * 16, 0));                   \
+                wrs, (wok && tap0 + k * TSTEP < 9) ? wbase + k * wstep : OOB, (c_) * 2 * Co * 16, 0));            \
     } while (0)
 
     // fragment base addresses (bytes)
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         for (int k = 0; k < NK; ++k) {
             const int p = p0 + k * PSTEP;
             const int row = p >> 5, col = p & 31;
-            if (full_tile || (ty0 + row < H && tx0 + col < W)) {
+            if (j * 8 < cvalid && (full_tile || (ty0 + row < H && tx0 + col < W))) {
                 uint4 v = *reinterpret_cast<const uint4*>(sbase + k * PSTEP * C::ERS);
                 *reinterpret_cast<uint4*>(ybase + ((long)row * W + col) * ldy) = v;
             }
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             float a = 0.f;
 #pragma unroll 8
             for (int k = 0; k < SL; ++k) a += rs[(which * SL + k) * BN + cc];
-            part[((long)pt * 2 + which) * Co + c0 + cc] = a;
+            if (cc < cvalid) part[((long)pt * 2 + which) * Co + c0 + cc] = a;
         }
     }
 #ifdef UMI_STAMP
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 template <int TH, int BN>
 int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H, int W,
            int Ci, int Co, hipStream_t s) {
-    const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = Co / BN;
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = (Co + BN - 1) / BN;
     const long nblk = (long)N * tiles_x * tiles_y * n_co;
     dim3 grid((unsigned)nblk), block(256);
 #define GO(HT, ST)                                                                                               \
@@ -351,7 +353,7 @@ bool umi_conv3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int 
     if (flags & (UMI_CONV_UPSAMPLE2 | UMI_CONV_FORCE_GENERIC)) return false;
     if (in_dtype != UMI_F16 || out_dtype != UMI_F16 || bias) return false;
     if (R != 3 || S != 3 || stride != 1 || pad != 1 || Ho != H || Wo != W) return false;
-    if (Ci % 16 || Co % 64 || ldx % 8 || ldy % 8) return false;
+    if (Ci % 16 || Co % 8 || ldx % 8 || ldy % 8) return false;
     if ((long)N * H * W * (long)(ldx > ldy ? ldx : ldy) >= (1L << 40)) return false;
     return true;
 }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
     const int wci = wave >> 1, wco = wave & 1;
     const int ci0 = (blockIdx.x / n_co_t) * 64, co0 = (blockIdx.x % n_co_t) * 64;
     if (HAS_TX) {
-        if (tid < 64) txs[tid] = tx[ci0 + tid];
+        if (tid < 64) txs[tid] = ci0 + tid < Ci ? tx[ci0 + tid] : make_float4(0.f, 1.f, 0.f, 0.f);
         __syncthreads();
     }
     const int t_begin = blockIdx.y * tiles_per_split;
@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
 
     // staging plan: A piece k -> halo pixel (tid>>3) + 32k, 8-channel group sub = tid & 7
     const int sub = tid & 7;
+    // channel counts that are not multiples of 64 (Ci, Co % 8 == 0, e.g. the 16-channel decoder tail): the missing
+    // 8-channel groups are staged as zeros and their outputs are not written
+    const bool a_on = ci0 + sub * 8 < Ci, b_on = co0 + sub * 8 < Co;
     int hyx[KPA];
 #pragma unroll
     for (int k = 0; k < KPA; ++k) {
@@ -101,13 +104,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
         const int ty0_ = (rm_ / tiles_x) * TR, tx0_ = (rm_ % tiles_x) * 32;                                     \
         _Pragma("unroll") for (int k = 0; k < KPA; ++k) {                                                       \
             int gy = ty0_ + (hyx[k] >> 8) - 1, gx = tx0_ + (hyx[k] & 255) - 1;                                  \
-            avalid[k] = hyx[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;                                  \
+            avalid[k] = a_on && hyx[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;                          \
             araw[k] = avalid[k] ? *reinterpret_cast<const half8*>(xin + ((long)((long)n_ * H + gy) * W + gx) * ldx) \
                                 : zero8;                                                                        \
         }                                                                                                       \
         _Pragma("unroll") for (int k = 0; k < KPB; ++k) {                                                       \
             int gy = ty0_ + k, gx = tx0_ + (tid >> 3);                                                          \
-            braw[k] = (gy < H && gx < W)                                                                        \
+            braw[k] = (b_on && gy < H && gx < W)                                                                \
                           ? *reinterpret_cast<const half8*>(din + ((long)((long)n_ * H + gy) * W + gx) * lddy)  \
                           : zero8;                                                                              \
         }                                                                                                       \
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            part[(((long)blockIdx.y * 9 + tap) * Ci + ci) * Co + co] = acc[tap][r];
+            if (ci < Ci && co < Co) part[(((long)blockIdx.y * 9 + tap) * Ci + ci) * Co + co] = acc[tap][r];
         }
 }
 
@@ -324,7 +327,7 @@ void plan(int N, int H, int W, int Ci, int Co, int* tiles_x, int* tiles_y, int* 
     *tiles_x = (W + 31) / 32;
     *tiles_y = (H + TR - 1) / TR;
     *tiles_total = N * (*tiles_x) * (*tiles_y);
-    const long pairs = (long)(Ci / 64) * (Co / 64);
+    const long pairs = (long)((Ci + 63) / 64) * ((Co + 63) / 64);
     long want = (1024 + pairs - 1) / pairs;             // ~2 resident workgroups per CU, two rounds
     const long slab = 9L * Ci * Co * 4;
     long cap = (96L << 20) / slab;                      // split-K slabs are written + re-read: bound that traffic
@@ -601,7 +604,7 @@ bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int
     if (flags & UMI_CONV_FORCE_GENERIC) return false;
     if (dtype != UMI_F16 || txb) return false;
     if (R != 3 || S != 3 || stride != 1 || pad != 1 || Ho != H || Wo != W) return false;
-    if (Ci % 64 || Co % 64 || ldx % 8 || lddy % 8) return false;
+    if (Ci % 8 || Co % 8 || ldx % 8 || lddy % 8) return false;      // partial 64-channel tiles are masked in the kernel
     return true;
 }
 
@@ -618,8 +621,8 @@ int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, i
     plan(N, H, W, Ci, Co, &tiles_x, &tiles_y, &tiles_total, &splits, &tps);
     if (ws_bytes < (size_t)splits * 9 * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
-    const int n_co_t = Co / 64;
-    dim3 grid((Ci / 64) * n_co_t, splits), block(256);
+    const int n_co_t = (Co + 63) / 64;
+    dim3 grid(((Ci + 63) / 64) * n_co_t, splits), block(256);
     if (txa)
         hipLaunchKernelGGL(wgrad3x3_mfma_kernel<true>, grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa,
                            (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps,
