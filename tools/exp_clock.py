@@ -25,7 +25,19 @@ x = torch.randn(n, h, w, ci, device="cuda").half()
 wt = torch.randn(co, ci, 3, 3, device="cuda") * 0.02
 y = torch.empty(n, h, w, co, device="cuda", dtype=torch.float16)
 pk = ops.pack_conv_fwd(wt, torch.float16, k8=True)
-ops.conv_fwd(x, None, lambda l: pk, None, y, 3, 3, 1, 1)
+dW = torch.empty(co, ci, 3, 3, device="cuda")
+tx = ops.passthrough_tx(ci, "cuda"); tx[:, 3] = 0
+MODE = os.environ.get("KERNEL", "fwd")
+
+
+def launch():
+    if MODE == "wgrad":
+        ops.conv_wgrad(x, tx, y, None, dW, ci * 9, 9, 1, 1.0, 3, 3, 1, 1)
+    else:
+        ops.conv_fwd(x, None, lambda l: pk, None, y, 3, 3, 1, 1)
+
+
+launch()
 torch.cuda.synchronize()
 th = threading.Thread(target=poll); th.start()
 time.sleep(1.0)
@@ -36,7 +48,7 @@ iters = 0
 e0.record()
 while time.time() - t0 < 6.0:
     for _ in range(200):
-        ops.conv_fwd(x, None, lambda l: pk, None, y, 3, 3, 1, 1)
+        launch()
     iters += 200
     torch.cuda.synchronize()
 e1.record(); torch.cuda.synchronize()
@@ -44,7 +56,8 @@ t_end = time.time()
 time.sleep(0.5)
 stop = True; th.join()
 ms = e0.elapsed_time(e1) / iters
-print(f"conv {ci}->{co}@{h}: {ms*1e3:.1f} us/launch, {2*n*h*w*ci*co*9/ms/1e9:.0f} TFLOP/s")
+print(f"{MODE} {ci}->{co}@{h}: {ms*1e3:.1f} us/launch, {2*n*h*w*ci*co*9/ms/1e9:.0f} TFLOP/s")
+import re
 for t, k in samples:
     tag = "idle" if t < t_idle else ("LOAD" if t < t_end else "after")
-    print(tag, " | ".join(k))
+    print(tag, " ".join(re.findall(r"(sclk|Power)[^(]*\(?W?\)?:? *\(?([0-9.]+)", " | ".join(k)).__repr__().split()))

@@ -29,6 +29,13 @@ __device__ __forceinline__ float umi_tx(float v, const float4 t) {
 // lo in {0, -inf}, so the result is bit-identical to (half)umi_tx((float)x, t) at ~1.5 instead of ~3 VALU ops/element.
 typedef _Float16 umi_half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ umi_half8 umi_tx8(umi_half8 v, const float4* t) {
+#ifdef UMI_EXP_TX_PK
+    // timing-only ablation (tools/exp_stamp_wgrad.py): packed fp16 fma with fp16 scale/shift -- NOT the shipped numerics
+    umi_half8 sc, sh, lo_;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = (half_t)t[j].y; sh[j] = (half_t)t[j].z; lo_[j] = (half_t)t[j].w; }
+    return __builtin_elementwise_max(v * sc + sh, lo_);
+#endif
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 in = __builtin_bit_cast(u32x4, v), out;
     umi_half8 lo;

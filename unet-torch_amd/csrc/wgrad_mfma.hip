@@ -16,6 +16,7 @@
 // 3 taps x 4 rows.  Split-K over pixel tiles; partial slabs [split][tap][ci][co] fp32 are reduced in
 // fixed order (deterministic) by wgrad_reduce_kernel into the parameter's own layout.
 #include "common.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -25,14 +26,27 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
                              long s_t, float scale, hipStream_t st);
 
+#ifdef UMI_STAMP
+// diagnostic build only (tools/exp_stamp_wgrad.py): per-wave cycle sums of the tile-loop segments
+__device__ unsigned long long umi_stamp_buf_w[2048 * 8];
+#define UMI_TW(var)                                                                       \
+    unsigned long long var;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0)
+extern "C" int umi_debug_read_stamps_w(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(umi_stamp_buf_w), sizeof(umi_stamp_buf_w));
+}
+#endif
+
 namespace {
 
 constexpr int TR = 4;                    // image rows per pixel tile
 constexpr int HPIX = (TR + 2) * 34;      // halo pixels
 constexpr int PROW = 64;                 // LDS bytes per pixel row of one 32-channel chunk
-constexpr int A_CHUNK = HPIX * PROW;     // 13056
+constexpr int A_CHUNK = HPIX * PROW + 64; // 13056 + 64: the two chunks' rows fall on opposite halves of the 128-B store bank window
 constexpr int A_BYTES = 2 * A_CHUNK;     // 64 input channels
-constexpr int B_CHUNK = TR * 32 * PROW;  // 8192
+constexpr int B_CHUNK = TR * 32 * PROW + 64;
 constexpr int B_BYTES = 2 * B_CHUNK;
 constexpr int SMEM = A_BYTES + B_BYTES;  // 42496
 constexpr int KPA = (HPIX * 8 + 255) / 256;   // 7 16-B pieces per thread for the halo
@@ -59,6 +73,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
     const int lane = tid & 63, wave = tid >> 6;
     const int wci = wave >> 1, wco = wave & 1;
     const int ci0 = (blockIdx.x / n_co_t) * 64, co0 = (blockIdx.x % n_co_t) * 64;
+#ifdef UMI_STAMP
+    UMI_TW(t_start);
+    unsigned long long seg[5] = {0, 0, 0, 0, 0};
+#endif
     if (HAS_TX) {
         if (tid < 64) txs[tid] = ci0 + tid < Ci ? tx[ci0 + tid] : make_float4(0.f, 1.f, 0.f, 0.f);
         __syncthreads();
@@ -67,22 +85,28 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
     int t_end = t_begin + tiles_per_split;
     if (t_end > tiles_total) t_end = tiles_total;
 
-    // staging plan: A piece k -> halo pixel (tid>>3) + 32k, 8-channel group sub = tid & 7
+    // staging plan: A piece k -> halo pixel (tid>>3) + 32k, 8-channel group sub = tid & 7.  Loads go through buffer
+    // descriptors over the whole tensors: voffset = tile origin (wave-uniform, carried incrementally: no divisions in the
+    // loop) + a per-thread constant, or an out-of-range offset (returns zeros) for padding / partial tiles / masked channels.
     const int sub = tid & 7;
     // channel counts that are not multiples of 64 (Ci, Co % 8 == 0, e.g. the 16-channel decoder tail): the missing
     // 8-channel groups are staged as zeros and their outputs are not written
     const bool a_on = ci0 + sub * 8 < Ci, b_on = co0 + sub * 8 < Co;
-    int hyx[KPA];
+    constexpr unsigned OOB = 0x7FFFFFFFu;
+    int hyx[KPA];                              // (hy-1) << 16 | (hx-1) & 0xffff of the halo pixel, or INT_MIN: no piece
+    int aoff[KPA];                             // byte offset of the piece relative to the tile's origin pixel
 #pragma unroll
     for (int k = 0; k < KPA; ++k) {
         int hp = (tid >> 3) + 32 * k;
         int hy = hp / 34, hx = hp - hy * 34;
-        hyx[k] = (hp < HPIX) ? (hy << 8) | hx : -1;
+        hyx[k] = (hp < HPIX && a_on) ? (int)(((unsigned)(hy - 1) << 16) | ((unsigned)(hx - 1) & 0xffffu)) : (int)0x80000000;
+        aoff[k] = (((hy - 1) * W + (hx - 1)) * ldx + ci0 + sub * 8) * 2;
     }
+    const int bcol = tid >> 3;
+    const int boff0 = (bcol * lddy + co0 + sub * 8) * 2;      // + k * W * lddy * 2 for image row k of the tile
     const int a_lds = (sub >> 2) * A_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;             // + k*32*PROW
     const int b_lds = A_BYTES + (sub >> 2) * B_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;   // + k*32*PROW
-    const half_t* xin = x + ci0 + sub * 8;
-    const half_t* din = dy + co0 + sub * 8;
+    const long ximg = (long)H * W * ldx, yimg = (long)H * W * lddy;      // elements per image (bytes < 2^31: host check)
 
     floatx16 acc[9];
 #pragma unroll
@@ -91,29 +115,37 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     half8 araw[KPA], braw[KPB];
-    half8 zero8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
     bool avalid[KPA];
 
-#define UMI_ISSUE(tile_)                                                                                         \
+    // tile cursor of the NEXT tile to issue (image, origin row / column)
+    int nx_n, nx_y, nx_x;
+    {
+        const int tpi = tiles_x * tiles_y;
+        nx_n = t_begin / tpi;
+        const int rm = t_begin - nx_n * tpi;
+        nx_y = (rm / tiles_x) * TR;
+        nx_x = (rm % tiles_x) * 32;
+    }
+#define UMI_ISSUE()                                                                                              \
     do {                                                                                                        \
-        const int tt = (tile_);                                                                                 \
-        const int n_ = tt / (tiles_x * tiles_y);                                                                \
-        const int rm_ = tt - n_ * tiles_x * tiles_y;                                                            \
-        const int ty0_ = (rm_ / tiles_x) * TR, tx0_ = (rm_ % tiles_x) * 32;                                     \
+        /* one descriptor per image (wave-uniform, SGPRs): offsets stay 32-bit whatever the batch size */        \
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + nx_n * ximg), 0, (int)(ximg * 2), 0x00020000); \
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + nx_n * yimg), 0, (int)(yimg * 2), 0x00020000); \
+        const int org = nx_y * W + nx_x;                                                                        \
+        const unsigned abase = (unsigned)org * (unsigned)(ldx * 2), bbase = (unsigned)org * (unsigned)(lddy * 2);  \
         _Pragma("unroll") for (int k = 0; k < KPA; ++k) {                                                       \
-            int gy = ty0_ + (hyx[k] >> 8) - 1, gx = tx0_ + (hyx[k] & 255) - 1;                                  \
-            avalid[k] = a_on && hyx[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;                          \
-            araw[k] = avalid[k] ? *reinterpret_cast<const half8*>(xin + ((long)((long)n_ * H + gy) * W + gx) * ldx) \
-                                : zero8;                                                                        \
+            const int gy = nx_y + (hyx[k] >> 16), gx = nx_x + (int)(short)(hyx[k] & 0xffff);                    \
+            avalid[k] = hyx[k] != (int)0x80000000 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;  \
+            araw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                          \
+                xrs, avalid[k] ? abase + (unsigned)aoff[k] : OOB, 0, 0));                                       \
         }                                                                                                       \
         _Pragma("unroll") for (int k = 0; k < KPB; ++k) {                                                       \
-            int gy = ty0_ + k, gx = tx0_ + (tid >> 3);                                                          \
-            braw[k] = (b_on && gy < H && gx < W)                                                                \
-                          ? *reinterpret_cast<const half8*>(din + ((long)((long)n_ * H + gy) * W + gx) * lddy)  \
-                          : zero8;                                                                              \
+            const bool ok = b_on && nx_y + k < H && nx_x + bcol < W;                                            \
+            braw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                          \
+                yrs, ok ? bbase + (unsigned)(boff0 + k * W * lddy * 2) : OOB, 0, 0));                           \
         }                                                                                                       \
+        nx_x += 32;                                                                                             \
+        if (nx_x >= W) { nx_x = 0; nx_y += TR; if (nx_y >= H) { nx_y = 0; ++nx_n; } }                           \
     } while (0)
 
     // per-lane fragment addresses for the transposing reads (see file header)
@@ -122,8 +154,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
     const unsigned char* a_frag = smem + wci * A_CHUNK + frag_lane;             // + ((rr*34) + 16*xh + dx) * PROW
     const unsigned char* b_frag = smem + A_BYTES + wco * B_CHUNK + frag_lane;   // + (r*32 + 16*xh) * PROW
 
-    if (t_begin < t_end) UMI_ISSUE(t_begin);
+    if (t_begin < t_end) UMI_ISSUE();
+#ifdef UMI_STAMP
+    UMI_TW(t_loop);
+#endif
     for (int tile = t_begin; tile < t_end; ++tile) {
+#ifdef UMI_STAMP
+        UMI_TW(t0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UMI_TW(t0b);
+#endif
         if (HAS_TX) {
             // re-read the 8 transform rows per tile (L1-resident) instead of pinning 32 registers across the
             // MFMA phase; the opaque zero keeps the loads from being hoisted out of the tile loop
@@ -140,35 +180,322 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
         }
 #pragma unroll
         for (int k = 0; k < KPA; ++k)
-            if (hyx[k] >= 0) *reinterpret_cast<half8*>(smem + a_lds + k * 32 * PROW) = araw[k];
+            if ((tid >> 3) + 32 * k < HPIX) *reinterpret_cast<half8*>(smem + a_lds + k * 32 * PROW) = araw[k];
 #pragma unroll
         for (int k = 0; k < KPB; ++k) *reinterpret_cast<half8*>(smem + b_lds + k * 32 * PROW) = braw[k];
+#ifdef UMI_STAMP
+        UMI_TW(t1);
+#endif
         __syncthreads();
-        if (tile + 1 < t_end) UMI_ISSUE(tile + 1);
+#ifdef UMI_STAMP
+        UMI_TW(t2);
+#endif
+        if (tile + 1 < t_end) UMI_ISSUE();
 
+        // (UMI_EXP_W_*: timing-only ablation builds of tools/exp_stamp_wgrad.py, never compiled into the shipped library)
 #pragma unroll
         for (int xh = 0; xh < 2; ++xh) {
             half8 bfr[TR];
 #pragma unroll
-            for (int r = 0; r < TR; ++r) bfr[r] = tr_frag(b_frag + (r * 32 + 16 * xh) * PROW);
+            for (int r = 0; r < TR; ++r) {
+#ifndef UMI_EXP_W_NO_FRAG
+                bfr[r] = tr_frag(b_frag + (r * 32 + 16 * xh) * PROW);
+#else
+                bfr[r] = braw[r];
+#endif
+            }
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 half8 afr[TR + 2];
 #pragma unroll
-                for (int rr = 0; rr < TR + 2; ++rr) afr[rr] = tr_frag(a_frag + (rr * 34 + 16 * xh + dx) * PROW);
+                for (int rr = 0; rr < TR + 2; ++rr) {
+#ifndef UMI_EXP_W_NO_FRAG
+                    afr[rr] = tr_frag(a_frag + (rr * 34 + 16 * xh + dx) * PROW);
+#else
+                    afr[rr] = araw[rr];
+#endif
+                }
 #pragma unroll
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
-                    for (int dyi = 0; dyi < 3; ++dyi)
+                    for (int dyi = 0; dyi < 3; ++dyi) {
+#ifndef UMI_EXP_W_NO_MFMA
                         acc[dyi * 3 + dx] =
                             __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[r + dyi], bfr[r], acc[dyi * 3 + dx], 0, 0, 0);
+#else
+                        asm volatile("" ::"v"(afr[r + dyi]), "v"(bfr[r]));
+#endif
+                    }
             }
         }
+#ifdef UMI_STAMP
+        UMI_TW(t3);
+#endif
         __syncthreads();
+#ifdef UMI_STAMP
+        UMI_TW(t4);
+        seg[0] += t0b - t0; seg[1] += t1 - t0b; seg[2] += t2 - t1; seg[3] += t3 - t2; seg[4] += t4 - t3;
+#endif
     }
 #undef UMI_ISSUE
+#ifdef UMI_STAMP
+    UMI_TW(t_ep0);
+#endif
 
     // partial slab: part[((z*9 + tap)*Ci + ci)*Co + co]
+    const int co = co0 + wco * 32 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (ci < Ci && co < Co) part[(((long)blockIdx.y * 9 + tap) * Ci + ci) * Co + co] = acc[tap][r];
+        }
+#ifdef UMI_STAMP
+    UMI_TW(t_end_);
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lane == 0 && bid < 512) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) umi_stamp_buf_w[(bid * 4 + wave) * 8 + i] = seg[i];
+        umi_stamp_buf_w[(bid * 4 + wave) * 8 + 5] = t_end - t_begin;
+        umi_stamp_buf_w[(bid * 4 + wave) * 8 + 6] = t_loop - t_start;
+        umi_stamp_buf_w[(bid * 4 + wave) * 8 + 7] = t_end_ - t_ep0;
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant of the kernel above: one workgroup of 8 waves per CU, LDS tile double-buffered.
+//   waves 0-3 (one per SIMD) = consumers: transposing fragment reads + the 72 MFMAs of a pixel tile, nothing else;
+//   waves 4-7 (one per SIMD) = producers: buffer loads -> consumer-side transform -> ds_write of the NEXT tile.
+// The hardware interleaves the two waves of a SIMD, so the staging VALU/LDS work runs under the MFMAs instead of
+// in series with them (in-kernel stamps of the single-role kernel: staging ~45 % of every tile iteration, and the
+// kernel is not power-limited: 1.2 kW at 2.4 GHz).  One barrier per tile.  Same math, same partial-slab layout.
+constexpr int WS_SMEM = 2 * SMEM;        // 84,992 B (dynamic LDS)
+
+template <bool HAS_TX>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
+    const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ dy, int lddy,
+    float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x, int tiles_y, int tiles_total,
+    int tiles_per_split, int n_co_t) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ws[];      // [2][SMEM] then txs[64]
+    float4* txs = reinterpret_cast<float4*>(smem_ws + WS_SMEM);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int ci0 = (blockIdx.x / n_co_t) * 64, co0 = (blockIdx.x % n_co_t) * 64;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    int t_end = t_begin + tiles_per_split;
+    if (t_end > tiles_total) t_end = tiles_total;
+    const int ntile = t_end - t_begin;
+    if (HAS_TX) {
+        if (tid < 64) txs[tid] = ci0 + tid < Ci ? tx[ci0 + tid] : make_float4(0.f, 1.f, 0.f, 0.f);
+        __syncthreads();
+    }
+
+    if (producer) {
+        // ---------------- producer waves: stage tile i+1 while the consumers work on tile i ----------------------------
+        const int ptid = tid - 256;
+        const int sub = ptid & 7;
+        const bool a_on = ci0 + sub * 8 < Ci, b_on = co0 + sub * 8 < Co;
+        constexpr unsigned OOB = 0x7FFFFFFFu;
+        int hyx[KPA], aoff[KPA];
+#pragma unroll
+        for (int k = 0; k < KPA; ++k) {
+            int hp = (ptid >> 3) + 32 * k;
+            int hy = hp / 34, hx = hp - hy * 34;
+            hyx[k] = (hp < HPIX && a_on) ? (int)(((unsigned)(hy - 1) << 16) | ((unsigned)(hx - 1) & 0xffffu)) : (int)0x80000000;
+            aoff[k] = (((hy - 1) * W + (hx - 1)) * ldx + ci0 + sub * 8) * 2;
+        }
+        const int bcol = ptid >> 3;
+        const int boff0 = (bcol * lddy + co0 + sub * 8) * 2;
+        const int a_lds = (sub >> 2) * A_CHUNK + (ptid >> 3) * PROW + (sub & 3) * 16;
+        const int b_lds = A_BYTES + (sub >> 2) * B_CHUNK + (ptid >> 3) * PROW + (sub & 3) * 16;
+        const long ximg = (long)H * W * ldx, yimg = (long)H * W * lddy;
+        // this thread's 8 transform rows stay in registers (a producer wave has no accumulators to make room for; read from
+        // LDS per tile they cost 12 ds_read2_b32 with 8-way bank conflicts: measured ~1.5k LDS cycles per tile)
+        float4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = HAS_TX ? txs[sub * 8 + j] : make_float4(0.f, 1.f, 0.f, 0.f);
+        // two register sets: the loads of tile i+2 stay in flight for a whole iteration while tile i+1 is transformed and
+        // written (with a single set the producer's iteration is the exposed global-load latency plus the stores)
+        half8 araw0[KPA], braw0[KPB], araw1[KPA], braw1[KPB];
+        bool avalid0[KPA], avalid1[KPA];
+        int nx_n, nx_y, nx_x;
+        {
+            const int tpi = tiles_x * tiles_y;
+            nx_n = t_begin / tpi;
+            const int rm = t_begin - nx_n * tpi;
+            nx_y = (rm / tiles_x) * TR;
+            nx_x = (rm % tiles_x) * 32;
+        }
+#ifdef UMI_EXP_WS_NO_LOAD      /* timing-only: every load out of range (returns zeros without touching memory) */
+#define UMI_EXP_LOAD_OK(c_) ((c_) && H < 0)
+#else
+#define UMI_EXP_LOAD_OK(c_) (c_)
+#endif
+#define UMI_ISSUE_WS(S)                                                                                          \
+    do {                                                                                                        \
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + nx_n * ximg), 0, (int)(ximg * 2), 0x00020000); \
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + nx_n * yimg), 0, (int)(yimg * 2), 0x00020000); \
+        const int org = nx_y * W + nx_x;                                                                        \
+        const unsigned abase = (unsigned)org * (unsigned)(ldx * 2), bbase = (unsigned)org * (unsigned)(lddy * 2);  \
+        _Pragma("unroll") for (int k = 0; k < KPA; ++k) {                                                       \
+            const int gy = nx_y + (hyx[k] >> 16), gx = nx_x + (int)(short)(hyx[k] & 0xffff);                    \
+            avalid##S[k] = hyx[k] != (int)0x80000000 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W; \
+            araw##S[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                       \
+                xrs, UMI_EXP_LOAD_OK(avalid##S[k]) ? abase + (unsigned)aoff[k] : OOB, 0, 0));                   \
+        }                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < KPB; ++k) {                                                       \
+            const bool ok = b_on && nx_y + k < H && nx_x + bcol < W;                                            \
+            braw##S[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                       \
+                yrs, UMI_EXP_LOAD_OK(ok) ? bbase + (unsigned)(boff0 + k * W * lddy * 2) : OOB, 0, 0));          \
+        }                                                                                                       \
+        nx_x += 32;                                                                                             \
+        if (nx_x >= W) { nx_x = 0; nx_y += TR; if (nx_y >= H) { nx_y = 0; ++nx_n; } }                           \
+    } while (0)
+#ifdef UMI_EXP_WS_NO_STORE
+#define UMI_STORE_WS(S, buf_)                                                                                    \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < KPA; ++k) asm volatile("" ::"v"(araw##S[k]));                     \
+        _Pragma("unroll") for (int k = 0; k < KPB; ++k) asm volatile("" ::"v"(braw##S[k]));                     \
+    } while (0)
+#else
+#define UMI_STORE_WS(S, buf_)                                                                                    \
+    do {                                                                                                        \
+        unsigned char* sb = smem_ws + (buf_) * SMEM;                                                            \
+        if (HAS_TX) {                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < KPA; ++k) {                                                   \
+                const half8 t8 = umi_tx8(araw##S[k], t);                                                        \
+                araw##S[k] = avalid##S[k] ? t8 : araw##S[k];      /* out-of-image pieces were loaded as zeros */ \
+            }                                                                                                   \
+        }                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < KPA; ++k)                                                         \
+            if ((ptid >> 3) + 32 * k < HPIX) *reinterpret_cast<half8*>(sb + a_lds + k * 32 * PROW) = araw##S[k]; \
+        _Pragma("unroll") for (int k = 0; k < KPB; ++k) *reinterpret_cast<half8*>(sb + b_lds + k * 32 * PROW) = braw##S[k]; \
+    } while (0)
+#endif
+
+        // tile j lives in register set j & 1 and goes to LDS buffer j & 1; issue order = tile order
+        if (ntile > 0) UMI_ISSUE_WS(0);
+        if (ntile > 1) UMI_ISSUE_WS(1);
+        if (ntile > 0) UMI_STORE_WS(0, 0);
+        if (ntile > 2) UMI_ISSUE_WS(0);
+        __syncthreads();                                    // tile 0 is in buffer 0
+#ifdef UMI_STAMP
+        unsigned long long pw = 0, pb = 0;
+#define UMI_PS(a_) UMI_TW(a_)
+#else
+#define UMI_PS(a_)
+#endif
+        for (int i = 0; i < ntile; i += 2) {
+            UMI_PS(q0);
+#ifndef UMI_EXP_WS_NO_PROD
+            if (i + 1 < ntile) {                            // consumers are on tile i (buffer 0)
+                UMI_STORE_WS(1, 1);
+                if (i + 3 < ntile) UMI_ISSUE_WS(1);
+            }
+#endif
+            UMI_PS(q1);
+            __syncthreads();
+            UMI_PS(q2);
+            if (i + 1 < ntile) {                            // consumers are on tile i + 1 (buffer 1)
+#ifndef UMI_EXP_WS_NO_PROD
+                if (i + 2 < ntile) {
+                    UMI_STORE_WS(0, 0);
+                    if (i + 4 < ntile) UMI_ISSUE_WS(0);
+                }
+#endif
+                UMI_PS(q3);
+                __syncthreads();
+                UMI_PS(q4);
+#ifdef UMI_STAMP
+                pw += q3 - q2; pb += q4 - q3;
+#endif
+            }
+#ifdef UMI_STAMP
+            pw += q1 - q0; pb += q2 - q1;
+#endif
+        }
+#ifdef UMI_STAMP
+        {
+            const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+            if (lane == 0 && bid < 256) {
+                umi_stamp_buf_w[(bid * 8 + wave) * 8 + 0] = pw;
+                umi_stamp_buf_w[(bid * 8 + wave) * 8 + 1] = pb;
+                umi_stamp_buf_w[(bid * 8 + wave) * 8 + 5] = ntile;
+            }
+        }
+#endif
+#undef UMI_PS
+#undef UMI_ISSUE_WS
+#undef UMI_STORE_WS
+        return;
+    }
+
+    // ---------------- consumer waves -------------------------------------------------------------------------------
+    const int wci = wave >> 1, wco = wave & 1;
+    floatx16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+    const int frag_lane = (8 * (g >> 1) + lq) * PROW + (16 * (g & 1) + 4 * lp) * 2;
+    __syncthreads();                                        // tile 0 staged
+    // A consumer wave is alone on its SIMD's matrix core: nothing hides its LDS latency but itself, so the fragments
+    // of step s+1 (a step = one (pixel-half, tap column): 12 MFMAs) are read while the MFMAs of step s run.
+#define UMI_LD_A(dst, xh_, dx_)                                                                                  \
+    _Pragma("unroll") for (int rr = 0; rr < TR + 2; ++rr) dst[rr] = tr_frag(a_frag + (rr * 34 + 16 * (xh_) + (dx_)) * PROW)
+#define UMI_LD_B(dst, xh_)                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < TR; ++r) dst[r] = tr_frag(b_frag + (r * 32 + 16 * (xh_)) * PROW)
+#define UMI_MMA(af_, bf_, dx_)                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < TR; ++r)                                                              \
+        _Pragma("unroll") for (int dyi = 0; dyi < 3; ++dyi)                                                     \
+            acc[dyi * 3 + (dx_)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[r + dyi], bf_[r], acc[dyi * 3 + (dx_)], 0, 0, 0)
+#define UMI_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef UMI_STAMP
+    unsigned long long cw = 0, cb = 0;
+#endif
+    for (int i = 0; i < ntile; ++i) {
+        const unsigned char* a_frag = smem_ws + (i & 1) * SMEM + wci * A_CHUNK + frag_lane;
+        const unsigned char* b_frag = smem_ws + (i & 1) * SMEM + A_BYTES + wco * B_CHUNK + frag_lane;
+        half8 a0[TR + 2], a1[TR + 2], b0[TR], b1[TR];
+#ifdef UMI_STAMP
+        UMI_TW(c0);
+#endif
+#ifndef UMI_EXP_WS_NO_CONS
+        UMI_LD_B(b0, 0); UMI_LD_A(a0, 0, 0); UMI_PIN();
+        UMI_LD_A(a1, 0, 1); UMI_PIN(); UMI_MMA(a0, b0, 0); UMI_PIN();
+        UMI_LD_A(a0, 0, 2); UMI_PIN(); UMI_MMA(a1, b0, 1); UMI_PIN();
+        UMI_LD_B(b1, 1); UMI_LD_A(a1, 1, 0); UMI_PIN(); UMI_MMA(a0, b0, 2); UMI_PIN();
+        UMI_LD_A(a0, 1, 1); UMI_PIN(); UMI_MMA(a1, b1, 0); UMI_PIN();
+        UMI_LD_A(a1, 1, 2); UMI_PIN(); UMI_MMA(a0, b1, 1); UMI_PIN();
+        UMI_MMA(a1, b1, 2);
+#endif
+#ifdef UMI_STAMP
+        UMI_TW(c1);
+#endif
+        __syncthreads();
+#ifdef UMI_STAMP
+        UMI_TW(c2);
+        cw += c1 - c0; cb += c2 - c1;
+#endif
+    }
+#ifdef UMI_STAMP
+    {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && bid < 256) {
+            umi_stamp_buf_w[(bid * 8 + wave) * 8 + 0] = cw;
+            umi_stamp_buf_w[(bid * 8 + wave) * 8 + 1] = cb;
+            umi_stamp_buf_w[(bid * 8 + wave) * 8 + 5] = ntile;
+        }
+    }
+#endif
+#undef UMI_LD_A
+#undef UMI_LD_B
+#undef UMI_MMA
+#undef UMI_PIN
     const int co = co0 + wco * 32 + (lane & 31);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -605,6 +932,7 @@ bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int
     if (dtype != UMI_F16 || txb) return false;
     if (R != 3 || S != 3 || stride != 1 || pad != 1 || Ho != H || Wo != W) return false;
     if (Ci % 8 || Co % 8 || ldx % 8 || lddy % 8) return false;      // partial 64-channel tiles are masked in the kernel
+    if ((long)H * W * (ldx > lddy ? ldx : lddy) * 2 >= 0x7FFFFFF0L) return false;   // 32-bit offsets inside one image
     return true;
 }
 
@@ -623,7 +951,23 @@ int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, i
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
     const int n_co_t = (Co + 63) / 64;
     dim3 grid(((Ci + 63) / 64) * n_co_t, splits), block(256);
-    if (txa)
+    static const bool classic = [] { const char* e = getenv("UMI_WGRAD_CLASSIC"); return e && e[0] == '1'; }();
+    if (!classic) {
+        constexpr int dyn = WS_SMEM + 64 * (int)sizeof(float4);
+        static const int attr_rc = [] {
+            int a = (int)hipFuncSetAttribute((const void*)wgrad3x3_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            int b = (int)hipFuncSetAttribute((const void*)wgrad3x3_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            return a ? a : b;
+        }();
+        if (attr_rc) return attr_rc;
+        dim3 block_ws(512);
+        if (txa)
+            hipLaunchKernelGGL(wgrad3x3_ws_kernel<true>, grid, block_ws, dyn, s, (const half_t*)x, ldx, (const float4*)txa,
+                               (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t);
+        else
+            hipLaunchKernelGGL(wgrad3x3_ws_kernel<false>, grid, block_ws, dyn, s, (const half_t*)x, ldx, (const float4*)txa,
+                               (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t);
+    } else if (txa)
         hipLaunchKernelGGL(wgrad3x3_mfma_kernel<true>, grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa,
                            (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps,
                            n_co_t);
