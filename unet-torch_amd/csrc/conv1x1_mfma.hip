@@ -141,8 +141,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     float4 txr = make_float4(0.f, 1.f, 0.f, 0.f);
     if (HAS_TX) {
         if (tid < CK) {
-            txbuf[0][tid] = UMI_TXROW(0);
-            if (nchunks > 1) txbuf[1][tid] = UMI_TXROW(1);
+            // stored transposed ([j][sub]): the 8 lanes of a pixel read 8 adjacent float4 (conflict-free) instead of 8 rows
+            // 128 B apart (one bank)
+            txbuf[0][(tid & 7) * 8 + (tid >> 3)] = UMI_TXROW(0);
+            if (nchunks > 1) txbuf[1][(tid & 7) * 8 + (tid >> 3)] = UMI_TXROW(1);
             if (nchunks > 2) txr = UMI_TXROW(2);
         }
         __syncthreads();
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         if (HAS_TX) {
             float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = txbuf[c & 1][sub * 8 + j];
+            for (int j = 0; j < 8; ++j) t[j] = txbuf[c & 1][j * 8 + sub];
 #pragma unroll
             for (int k = 0; k < KPX; ++k)
                 if (xv[k]) {
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         for (int k = 0; k < KPW; ++k) *reinterpret_cast<half8*>(smem + wl + k * 32 * ROWB) = wraw[k];
         __syncthreads();
         if (HAS_TX && tid < CK && c + 2 < nchunks) {
-            txbuf[c & 1][tid] = txr;                  // all readers of this buffer are past the barrier above
+            txbuf[c & 1][(tid & 7) * 8 + (tid >> 3)] = txr;                  // all readers of this buffer are past the barrier above
             if (c + 3 < nchunks) txr = UMI_TXROW(c + 3);
         }
         if (c + 1 < nchunks) UMI_ISSUE(c + 1);

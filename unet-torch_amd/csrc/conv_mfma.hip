@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #define UMI_CHUNK(i_) (i_)
     if (HAS_TX) {
         if (tid < 16) {
-            txbuf[0][tid] = tx[tid];
-            if (nchunks > 1) txbuf[1][tid] = tx[16 + tid];
+            // stored transposed ([j][q]: the two channel halves of a chunk side by side) so that the per-chunk reads of
+            // lanes q = 0 / 1 fall on different LDS banks
+            txbuf[0][(tid & 7) * 2 + (tid >> 3)] = tx[tid];
+            if (nchunks > 1) txbuf[1][(tid & 7) * 2 + (tid >> 3)] = tx[16 + tid];
         }
         __syncthreads();
     }
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         if (HAS_TX) {
             float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = txbuf[ci_ & 1][q * 8 + j];
+            for (int j = 0; j < 8; ++j) t[j] = txbuf[ci_ & 1][j * 2 + q];
 #pragma unroll
             for (int k = 0; k < C::KPH; ++k) {
                 if (hoff[k] != OOB) {
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         UMI_T(t2);
 #endif
         if (HAS_TX && tid < 16 && ci_ + 2 < nchunks) {
-            txbuf[ci_ & 1][tid] = txr;                        // every thread is past its reads of this buffer (barrier above)
+            txbuf[ci_ & 1][(tid & 7) * 2 + (tid >> 3)] = txr;                        // every thread is past its reads of this buffer (barrier above)
             if (ci_ + 3 < nchunks) txr = tx[(ci_ + 3) * 16 + tid];
         }
         if (ci_ + 1 < nchunks) UMI_ISSUE(UMI_CHUNK(ci_ + 1));

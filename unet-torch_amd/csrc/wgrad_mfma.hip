@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
     unsigned long long seg[5] = {0, 0, 0, 0, 0};
 #endif
     if (HAS_TX) {
-        if (tid < 64) txs[tid] = ci0 + tid < Ci ? tx[ci0 + tid] : make_float4(0.f, 1.f, 0.f, 0.f);
+        // stored transposed ([j][sub]) so that the 8 channel groups read 8 adjacent float4 (conflict-free)
+        if (tid < 64) txs[(tid & 7) * 8 + (tid >> 3)] = ci0 + tid < Ci ? tx[ci0 + tid] : make_float4(0.f, 1.f, 0.f, 0.f);
         __syncthreads();
     }
     const int t_begin = blockIdx.y * tiles_per_split;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
             asm volatile("" : "+v"(opaque));
             float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = txs[sub * 8 + j + opaque];
+            for (int j = 0; j < 8; ++j) t[j] = txs[j * 8 + sub + opaque];
 #pragma unroll
             for (int k = 0; k < KPA; ++k)
                 if (avalid[k]) {
@@ -289,7 +290,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
     if (t_end > tiles_total) t_end = tiles_total;
     const int ntile = t_end - t_begin;
     if (HAS_TX) {
-        if (tid < 64) txs[tid] = ci0 + tid < Ci ? tx[ci0 + tid] : make_float4(0.f, 1.f, 0.f, 0.f);
+        // stored transposed ([j][sub]) so that the 8 channel groups read 8 adjacent float4 (conflict-free)
+        if (tid < 64) txs[(tid & 7) * 8 + (tid >> 3)] = ci0 + tid < Ci ? tx[ci0 + tid] : make_float4(0.f, 1.f, 0.f, 0.f);
         __syncthreads();
     }
 
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
         // LDS per tile they cost 12 ds_read2_b32 with 8-way bank conflicts: measured ~1.5k LDS cycles per tile)
         float4 t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = HAS_TX ? txs[sub * 8 + j] : make_float4(0.f, 1.f, 0.f, 0.f);
+        for (int j = 0; j < 8; ++j) t[j] = HAS_TX ? txs[j * 8 + sub] : make_float4(0.f, 1.f, 0.f, 0.f);
         // two register sets: the loads of tile i+2 stay in flight for a whole iteration while tile i+1 is transformed and
         // written (with a single set the producer's iteration is the exposed global-load latency plus the stores)
         half8 araw0[KPA], braw0[KPB], araw1[KPA], braw1[KPB];
@@ -514,8 +516,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
 // its own row address to ds_read_b64_tr_b16.  Tile = 2 low-res rows x 32 pixels; 4 accumulator tiles per wave.
 constexpr int T2R = 2;                                   // low-res rows per tile
 constexpr int X2_PIX = 2 * T2R * 64;                     // hi-res pixels per tile (4 rows x 64)
-constexpr int X2_CHUNK = X2_PIX * PROW;                  // 16384
-constexpr int Y2_CHUNK = T2R * 32 * PROW;                // 4096
+constexpr int X2_CHUNK = X2_PIX * PROW + 64;             // +64: chunk pairs on opposite halves of the store bank window
+constexpr int Y2_CHUNK = T2R * 32 * PROW + 64;
 constexpr int SMEM2 = 2 * X2_CHUNK + 2 * Y2_CHUNK;       // 40960
 constexpr int KPX2 = X2_PIX * 8 / 256;                   // 8
 constexpr int KPY2 = T2R * 32 * 8 / 256;                 // 2
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
     const int wcx = wave >> 1, wcy = wave & 1;
     const int cx0 = (blockIdx.x / n_cy_t) * 64, cy0 = (blockIdx.x % n_cy_t) * 64;
     if (HAS_TX) {
-        if (tid < 64) txs[tid] = txy[cy0 + tid];
+        if (tid < 64) txs[(tid & 7) * 8 + (tid >> 3)] = txy[cy0 + tid];      // transposed: see wgrad3x3
         __syncthreads();
     }
     const int t_begin = blockIdx.y * tiles_per_split;
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
             asm volatile("" : "+v"(opaque));
             float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = txs[sub * 8 + j + opaque];
+            for (int j = 0; j < 8; ++j) t[j] = txs[j * 8 + sub + opaque];
 #pragma unroll
             for (int k = 0; k < KPY2; ++k)
                 if (yvalid[k]) {
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
                                                                int tiles_total, int tiles_per_split, int n_co_t, WGeo geo) {
     constexpr int MT = TM / 64;                       // 32x32 tiles per wave per dimension
     constexpr int NCH = TM / 32;                      // 32-channel chunks per operand
-    constexpr int CHB = 64 * PROW;                    // bytes per chunk (64 pixel rows)
+    constexpr int CHB = 64 * PROW + 64;               // bytes per chunk (64 pixel rows; +64: see A_CHUNK)
     constexpr int PPP = TM / 8;                       // 16-B pieces per pixel
     constexpr int PXS = 256 / PPP;                    // pixels staged per pass
     constexpr int KP = 64 / PXS;                      // passes
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
     const int wci = wave >> 1, wco = wave & 1;
     const int ci0 = (blockIdx.x / n_co_t) * TM, co0 = (blockIdx.x % n_co_t) * TM;
     if (HAS_TX) {
-        if (tid < TM) txs[tid] = tx[ci0 + tid];
+        if (tid < TM) txs[(tid & 7) * PPP + (tid >> 3)] = tx[ci0 + tid];     // transposed [j][sub]: conflict-free reads
         __syncthreads();
     }
     const int t_begin = blockIdx.y * tiles_per_split;
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
             asm volatile("" : "+v"(opaque));
             float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = txs[sub * 8 + j + opaque];
+            for (int j = 0; j < 8; ++j) t[j] = txs[j * PPP + sub + opaque];
 #pragma unroll
             for (int k = 0; k < KP; ++k)
                 if (xval[k]) {
