@@ -23,7 +23,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int P = 256;        // pixels per workgroup tile
+// pixels per workgroup tile: template parameter P (256, or 128 when the grid would not fill the chip)
 constexpr int CK = 64;        // K chunk
 constexpr int ROWB = 144;     // LDS row bytes (64 halfs + 16 B pad)
 
@@ -34,7 +34,7 @@ struct Geo {                  // geometry of the (optionally strided) source / d
     int S, stride, pad, frac; // GATHER: taps per row, stride, padding; frac = data gradient of a strided conv
 };
 
-template <int BN, bool GATHER, bool OUT_UPS, bool HAS_TX>
+template <int P, int BN, bool GATHER, bool OUT_UPS, bool HAS_TX>
 __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     const float* __restrict__ bias, half_t* __restrict__ y, int ldy, long M, int Kc /*channels per tap of the source*/,
@@ -233,14 +233,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     }
 }
 
-template <int BN>
+template <int P, int BN>
 int launch(bool s2d, bool ups, const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y,
            int ldy, long M, int Kc, int Nc, int Ntot, int ntaps, Geo geo, hipStream_t s) {
     const int n_co = Ntot / BN;
     const long nblk = ((M + P - 1) / P) * n_co;
     dim3 grid((unsigned)nblk), block(256);
 #define GO(S2D, UPS, HT)                                                                                          \
-    hipLaunchKernelGGL((conv1x1_mfma_kernel<BN, S2D, UPS, HT>), grid, block, 0, s, (const half_t*)x, ldx,         \
+    hipLaunchKernelGGL((conv1x1_mfma_kernel<P, BN, S2D, UPS, HT>), grid, block, 0, s, (const half_t*)x, ldx,      \
                        (const float4*)tx, (const half_t*)wp8, bias, (half_t*)y, ldy, M, Kc, Nc, n_co, ntaps, geo)
     if (s2d) { if (tx) GO(true, false, true); else GO(true, false, false); }
     else if (ups) { if (tx) GO(false, true, true); else GO(false, true, false); }
@@ -292,7 +292,16 @@ int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, co
         M = (long)N * Ho * Wo;
         ntaps = R * S;
     }
-    if (Ntot % 128 == 0)
-        return launch<128>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s);
-    return launch<64>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s);
+    // largest tile that still gives every CU two workgroups; small GEMMs (ViT linears: 4,704 tokens x 768) take
+    // 128-pixel tiles, and 64-channel ones if that is still not enough
+    const bool bn128 = Ntot % 128 == 0;
+    const long want = 400;                                  // ~0.8 of the 512 resident workgroup slots
+    const long b_256_128 = ((M + 255) / 256) * (Ntot / 128), b_128_128 = ((M + 127) / 128) * (Ntot / 128);
+    const long b_256_64 = ((M + 255) / 256) * (Ntot / 64);
+#define GO(P_, BN_) return launch<P_, BN_>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s)
+    if (bn128 && b_256_128 >= want) GO(256, 128);
+    if (b_256_64 >= want) GO(256, 64);
+    if (bn128 && b_128_128 >= want) GO(128, 128);
+    GO(128, 64);
+#undef GO
 }
