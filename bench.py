@@ -94,9 +94,20 @@ def measure_conv_roofline(device, dtype, cin, f, H, W, B, reps=5):
             tot_t += ms
         del x, y, wgt, wp
     ach = tot_fl / tot_t / 1e9
+    # HBM-side bytes per launch come from the committed PMC passes of the same 17 launches (tools/prof_traffic.py:
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE); PMC collection
+    # cannot run inside this process, so the figure is read from profiles/ and null when that file is absent
+    traffic, traffic_note = None, None
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_fwd_traffic.json")
+    if os.path.exists(tf) and (cin, f, H, W, B) == (1, 64, 512, 512, 16):
+        with open(tf) as fh:
+            tj = json.load(fh)
+        traffic = tj["hbm_bytes_per_launch_avg"]
+        traffic_note = (f"avg bytes/launch over the 17 launches from {os.path.basename(tf)}; algorithmic "
+                        f"{tj['algorithmic_bytes_total'] // 17} B/launch (ratio {tj['ratio']}); counters include Infinity-Cache hits")
     return {"bound": "mfma", "kernel": "conv3x3 forward (+BN-stat epilogue, BN/ReLU-on-load), 17 DoubleConv launches",
             "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None, "per_launch": per}
+            "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note, "per_launch": per}
 
 
 def cpu_baseline(cin, ncls, f, H, W, budget_s=25.0):

@@ -824,7 +824,12 @@ bool umi_wgrad1x1_mfma_ok(long M, int Ci, int Co, int R, int S, int stride, int 
     if (M * (long)(ldx > lddy ? ldx : lddy) * 2 >= 0x7FFFFFF0L) return false;     // 32-bit buffer offsets
     return true;
 }
-static int wgrad1x1_tm(int Ci, int Co) { return (Ci % 128 == 0 && Co % 128 == 0) ? 128 : 64; }
+// 128 x 128 channel tiles only when there are enough of them to fill the chip without a deep split-K: every split is a
+// slab written and re-read by the reduction (a 768 x 768 linear over 4,704 tokens: 36 tiles x 25 splits = 59 MB of
+// slabs with 128-tiles, 144 x 8 = 19 MB with 64-tiles)
+static int wgrad1x1_tm(int Ci, int Co) {
+    return (Ci % 128 == 0 && Co % 128 == 0 && (long)(Ci / 128) * (Co / 128) >= 96) ? 128 : 64;
+}
 
 size_t umi_wgrad1x1_mfma_ws_bytes(long M, int Ci, int Co) {
     int tt, splits, tps;
