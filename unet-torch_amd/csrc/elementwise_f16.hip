@@ -7,7 +7,13 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int RPB = 512;       // pixel rows per stage-1 block of the BN-backward reduction
+// pixel rows per stage-1 block of the BN-backward reduction: sized so that every layer launches ~2,048 workgroups
+// (a fixed 512 left the 32x32 / 64x64 layers with 32-128 workgroups on 256 CUs)
+static int rpb_for(long M) {
+    long r = (M + 2047) / 2048;
+    r = (r + 63) / 64 * 64;
+    return (int)(r < 64 ? 64 : (r > 2048 ? 2048 : r));
+}
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -15,7 +21,7 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 __global__ __launch_bounds__(256) void bn_bwd_reduce1_v8(const half_t* __restrict__ da, int ldda,
                                                          const half_t* __restrict__ y, int ldy,
                                                          const float4* __restrict__ tx, const float* __restrict__ rstd,
-                                                         float* __restrict__ ws, long M, int C) {
+                                                         float* __restrict__ ws, long M, int C, int RPB) {
     __shared__ float red[2][256][9];               // [which][thread][8 channels] (+1 pad: conflict-free column sums)
     const int tid = threadIdx.x;
     const int G = C >> 3;                          // channel groups of 8; G divides 256
@@ -31,18 +37,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce1_v8(const half_t* __restric
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-    for (long r = r0 + pl; r < r1; r += PL) {
+#define UMI_BNB_ACC(yv_, gv_)                                          \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                    \
+        float yy = (float)yv_[j];                                      \
+        float z = umi_tx_pre(yy, t[j]);                                \
+        float dz = z > t[j].w ? (float)gv_[j] : 0.f;                   \
+        s[j] += dz;                                                    \
+        q[j] = fmaf(dz, (yy - t[j].x) * rs[j], q[j]);                  \
+    }
+    long r = r0 + pl;
+    for (; r + PL < r1; r += 2 * PL) {             // two rows per trip: four 16-B loads in flight per thread
+        half8 yv0 = *reinterpret_cast<const half8*>(y + r * ldy + cg * 8);
+        half8 gv0 = *reinterpret_cast<const half8*>(da + r * ldda + cg * 8);
+        half8 yv1 = *reinterpret_cast<const half8*>(y + (r + PL) * ldy + cg * 8);
+        half8 gv1 = *reinterpret_cast<const half8*>(da + (r + PL) * ldda + cg * 8);
+        UMI_BNB_ACC(yv0, gv0)
+        UMI_BNB_ACC(yv1, gv1)
+    }
+    if (r < r1) {
         half8 yv = *reinterpret_cast<const half8*>(y + r * ldy + cg * 8);
         half8 gv = *reinterpret_cast<const half8*>(da + r * ldda + cg * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float yy = (float)yv[j];
-            float z = umi_tx_pre(yy, t[j]);
-            float dz = z > t[j].w ? (float)gv[j] : 0.f;
-            s[j] += dz;
-            q[j] = fmaf(dz, (yy - t[j].x) * rs[j], q[j]);
-        }
+        UMI_BNB_ACC(yv, gv)
     }
+#undef UMI_BNB_ACC
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[0][tid][j] = s[j]; red[1][tid][j] = q[j]; }
     __syncthreads();
@@ -53,6 +70,43 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce1_v8(const half_t* __restric
         float a = 0.f;
         for (int k = 0; k < PL; ++k) a += red[which][k * G + g][j];
         ws[((long)blockIdx.x * 2 + which) * C + c] = a;
+    }
+}
+
+// ---- per-channel column sums (bias gradients: ConvTranspose2d / Linear biases), stage 1 -------------------------------
+__global__ __launch_bounds__(256) void colsum_v8(const half_t* __restrict__ x, int ldx, float* __restrict__ ws, long M, int C,
+                                                 int RPB) {
+    __shared__ float red[256][9];
+    const int tid = threadIdx.x;
+    const int G = C >> 3, PL = 256 / G;
+    const int cg = tid % G, pl = tid / G;
+    const long r0 = (long)blockIdx.x * RPB;
+    long r1 = r0 + RPB;
+    if (r1 > M) r1 = M;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+    long r = r0 + pl;
+    for (; r + 3 * PL < r1; r += 4 * PL) {         // four independent 16-B loads in flight per thread
+        half8 a = *reinterpret_cast<const half8*>(x + r * ldx + cg * 8);
+        half8 b = *reinterpret_cast<const half8*>(x + (r + PL) * ldx + cg * 8);
+        half8 c = *reinterpret_cast<const half8*>(x + (r + 2 * PL) * ldx + cg * 8);
+        half8 d = *reinterpret_cast<const half8*>(x + (r + 3 * PL) * ldx + cg * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] += (float)a[j] + (float)c[j]; s1[j] += (float)b[j] + (float)d[j]; }
+    }
+    for (; r < r1; r += PL) {
+        half8 a = *reinterpret_cast<const half8*>(x + r * ldx + cg * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s0[j] += (float)a[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid][j] = s0[j] + s1[j];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f;
+        for (int k = 0; k < PL; ++k) a += red[k * G + (c >> 3)][c & 7];
+        ws[((long)blockIdx.x * 2 + 0) * C + c] = a;
     }
 }
 
@@ -202,14 +256,24 @@ int grid_for(long items) {
 
 }  // namespace
 
-int umi_bn_bwd_rpb_f16v() { return RPB; }
+int umi_bn_bwd_rpb_f16v(long M) { return rpb_for(M); }
+
+// rows of partial sums the vectorised column-sum writes (layout [rows][2][C], slot 0 used), or 0 when it does not apply
+int umi_colsum_rows_f16v(long M, int C) { return (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) ? (int)((M + rpb_for(M) - 1) / rpb_for(M)) : 0; }
+bool umi_colsum_f16v(const void* x, int ldx, float* ws, long M, int C, hipStream_t s) {
+    if (!umi_colsum_rows_f16v(M, C) || ldx % 8 || !al16(x)) return false;
+    const int rpb = rpb_for(M);
+    hipLaunchKernelGGL(colsum_v8, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, s, (const half_t*)x, ldx, ws, M, C, rpb);
+    return true;
+}
 
 bool umi_bn_bwd_reduce1_f16v(const void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd, float* ws,
                              long M, int C, hipStream_t s) {
     if (!vec_ok(C, ldda, ldy, da, y)) return false;
-    int rows = (int)((M + RPB - 1) / RPB);
+    const int rpb = rpb_for(M);
+    int rows = (int)((M + rpb - 1) / rpb);
     hipLaunchKernelGGL(bn_bwd_reduce1_v8, dim3(rows), dim3(256), 0, s, (const half_t*)da, ldda, (const half_t*)y, ldy,
-                       (const float4*)tx, rstd, ws, M, C);
+                       (const float4*)tx, rstd, ws, M, C, rpb);
     return true;
 }
 

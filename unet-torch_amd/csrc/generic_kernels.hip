@@ -5,7 +5,9 @@
 #include "common.h"
 
 // elementwise_f16.hip: 16-B vectorised fp16 fast paths (return false when the shape does not qualify)
-int umi_bn_bwd_rpb_f16v();
+int umi_bn_bwd_rpb_f16v(long M);
+int umi_colsum_rows_f16v(long M, int C);
+bool umi_colsum_f16v(const void* x, int ldx, float* ws, long M, int C, hipStream_t s);
 bool umi_bn_bwd_reduce1_f16v(const void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd, float* ws,
                              long M, int C, hipStream_t s);
 bool umi_bn_bwd_apply_f16v(void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd,
@@ -509,7 +511,8 @@ __global__ void bn_bwd_apply_kernel(T* __restrict__ da, int ldda, const T* __res
 }
 
 extern "C" size_t umi_bn_bwd_ws_bytes(long M, int C) {
-    return (size_t)umi_cdiv(M, BNB_RPB) * 2 * (size_t)C * sizeof(float);
+    const int a = umi_cdiv(M, BNB_RPB), b = umi_cdiv(M, umi_bn_bwd_rpb_f16v(M));       // whichever path needs more rows
+    return (size_t)(a > b ? a : b) * 2 * (size_t)C * sizeof(float);
 }
 
 extern "C" int umi_bn_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const void* tx, const float* rstd,
@@ -521,7 +524,7 @@ extern "C" int umi_bn_bwd_reduce(const void* da, int ldda, const void* y, int ld
     hipStream_t s = (hipStream_t)stream;
     if (dtype == UMI_F16 && umi_bn_bwd_reduce1_f16v(da, ldda, y, ldy, tx, rstd, (float*)ws, M, C, s)) {
         UMI_LAUNCH_CHECK();
-        rows = umi_cdiv(M, umi_bn_bwd_rpb_f16v());
+        rows = umi_cdiv(M, umi_bn_bwd_rpb_f16v(M));
         hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, rows, C, sum_dz, sum_dzx, 1.f);
         UMI_LAUNCH_CHECK();
         return UMI_OK;
@@ -593,7 +596,8 @@ static void colsum_plan(long M, int C, int* splits, long* rps) {
 extern "C" size_t umi_colsum_ws_bytes(long M, int C) {
     int splits; long rps;
     colsum_plan(M, C, &splits, &rps);
-    return (size_t)splits * 2 * (size_t)C * sizeof(float);
+    const int vrows = umi_colsum_rows_f16v(M, C);
+    return (size_t)(splits > vrows ? splits : vrows) * 2 * (size_t)C * sizeof(float);
 }
 
 extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, long M, int C, int dtype, void* ws,
@@ -603,6 +607,13 @@ extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, l
     int splits; long rps;
     colsum_plan(M, C, &splits, &rps);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F16 && umi_colsum_f16v(x, ldx, (float*)ws, M, C, s)) {
+        UMI_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, umi_colsum_rows_f16v(M, C), C, out,
+                           (float*)nullptr, out_scale);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     dim3 grid((C + 63) / 64, splits);
     if (dtype == UMI_F32) hipLaunchKernelGGL(colsum1_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, (float*)ws, M, C, rps, out, out_scale);
     else if (dtype == UMI_F16) hipLaunchKernelGGL(colsum1_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, ldx, (float*)ws, M, C, rps, out, out_scale);
