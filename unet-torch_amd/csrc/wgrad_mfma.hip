@@ -640,7 +640,8 @@ void planT(int N, int h, int w, int Cx, int Cy, int* tiles_x, int* tiles_y, int*
     *tiles_y = (h + T2R - 1) / T2R;
     *tiles_total = N * (*tiles_x) * (*tiles_y);
     const long pairs = (long)(Cx / 64) * (Cy / 64);
-    long want = (1024 + pairs - 1) / pairs;
+    static const long target2 = [] { const char* e = getenv("UMI_WGRAD_SPLIT_TARGET2"); long v = e ? atol(e) : 0; return v > 0 ? v : 1024L; }();
+    long want = (target2 + pairs - 1) / pairs;
     const long slab = 4L * Cx * Cy * 4;
     long cap = (64L << 20) / slab;
     if (cap < 1) cap = 1;
@@ -657,11 +658,14 @@ void plan(int N, int H, int W, int Ci, int Co, int* tiles_x, int* tiles_y, int* 
     *tiles_y = (H + TR - 1) / TR;
     *tiles_total = N * (*tiles_x) * (*tiles_y);
     const long pairs = (long)((Ci + 63) / 64) * ((Co + 63) / 64);
-    long want = (1024 + pairs - 1) / pairs;             // ~2 resident workgroups per CU, two rounds
+    // one 8-wave workgroup per CU resident: ONE balanced round of ~256 workgroups measured best (553 / 566 / 572 img/s for
+    // targets 1024 / 512 / 256 on one box: every split is a slab written and re-read); UMI_WGRAD_SPLIT_TARGET overrides
+    static const long target = [] { const char* e = getenv("UMI_WGRAD_SPLIT_TARGET"); long v = e ? atol(e) : 0; return v > 0 ? v : 256L; }();
+    long want = (target + pairs - 1) / pairs;
     const long slab = 9L * Ci * Co * 4;
     long cap = (96L << 20) / slab;                      // split-K slabs are written + re-read: bound that traffic
     if (cap < 1) cap = 1;
-    if (pairs * cap < 512 && pairs < 512) cap = (512 + pairs - 1) / pairs;   // but never starve the chip
+    if (pairs * cap < 256 && pairs < 256) cap = (256 + pairs - 1) / pairs;   // but never starve the chip
     if (want > cap) want = cap;
     if (want > *tiles_total) want = *tiles_total;
     if (want < 1) want = 1;
@@ -801,7 +805,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
 void plan1(long M, int Ci, int Co, int TM, int* tiles_total, int* splits, int* tps, int taps = 1) {
     *tiles_total = (int)((M + 63) / 64);
     const long pairs = (long)(Ci / TM) * (Co / TM) * taps;
-    long want = (1024 + pairs - 1) / pairs;
+    static const long target2 = [] { const char* e = getenv("UMI_WGRAD_SPLIT_TARGET2"); long v = e ? atol(e) : 0; return v > 0 ? v : 1024L; }();
+    long want = (target2 + pairs - 1) / pairs;
     const long slab = (long)taps * Ci * Co * 4;
     long cap = (64L << 20) / slab;
     if (cap < 1) cap = 1;
