@@ -23,6 +23,7 @@
 // per-channel sum / sum-of-squares of the *stored* values (BatchNorm statistics) are taken column-wise
 // from that LDS tile and written as one deterministic partial row per pixel tile.
 #include "common.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -68,7 +69,7 @@ template <int TH, int BN, bool HAS_TX, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     half_t* __restrict__ y, int ldy, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x,
-    int tiles_y, int n_co) {
+    int tiles_y, int n_co, int xcd_chunk) {
     using C = Cfg<TH, BN>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];
     // consumer-transform rows of the current / next chunk (16 channels x float4), refilled two chunks ahead so the
@@ -84,8 +85,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     UMI_T(t_start);
 #endif
 
-    const int cb = blockIdx.x % n_co;
-    const int pt = blockIdx.x / n_co;
+    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so id -> work item
+    // is permuted to give every XCD a contiguous range of (pixel tile, channel block) items: the channel blocks of one
+    // pixel tile then share an L2 and the input tile crosses the fabric once instead of once per channel block
+    int wid = blockIdx.x;
+    if (xcd_chunk > 0 && wid < 8 * xcd_chunk) wid = (wid & 7) * xcd_chunk + (wid >> 3);
+    const int cb = wid % n_co;
+    const int pt = wid / n_co;
     const int n = pt / (tiles_x * tiles_y);
     const int rem = pt - n * tiles_x * tiles_y;
     const int ty0 = (rem / tiles_x) * TH, tx0 = (rem % tiles_x) * 32;
@@ -334,10 +340,12 @@ int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int
     const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = (Co + BN - 1) / BN;
     const long nblk = (long)N * tiles_x * tiles_y * n_co;
     dim3 grid((unsigned)nblk), block(256);
+    static const bool xcd_off = [] { const char* e = getenv("UMI_CONV_NO_XCD_ORDER"); return e && e[0] == '1'; }();
+    const int xcd_chunk = (n_co > 1 && !xcd_off) ? (int)(nblk / 8) : 0;     // ids beyond 8 * chunk (the remainder) keep their order
 #define GO(HT, ST)                                                                                               \
     hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, ST>), grid, block, 0, s, (const half_t*)x, ldx,          \
                        (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
-                       tiles_y, n_co)
+                       tiles_y, n_co, xcd_chunk)
     if (tx) { if (part) GO(true, true); else GO(true, false); }
     else    { if (part) GO(false, true); else GO(false, false); }
 #undef GO
