@@ -216,10 +216,7 @@ class DecoderCup(nn.Module):
 def _build_block(t, h, blk: Block, cfg):
     heads = cfg.transformer["num_heads"]
     x = t.layer_norm(h, blk.attention_norm)
-    q = t.linear(x, blk.attn.query.weight, blk.attn.query.bias)
-    k = t.linear(x, blk.attn.key.weight, blk.attn.key.bias)
-    v = t.linear(x, blk.attn.value.weight, blk.attn.value.bias)
-    ctx = t.attention(q, k, v, heads)                                  # attn_dropout rate is 0.0 in every config
+    ctx = t.qkv_attention(x, blk.attn.query, blk.attn.key, blk.attn.value, heads)   # attn_dropout rate is 0.0 in every config
     if cfg.transformer["attention_dropout_rate"] > 0 and t.training:
         raise NotImplementedError("attention-probability dropout > 0 is not supported (all reference configs use 0.0)")
     a = t.linear(ctx, blk.attn.out.weight, blk.attn.out.bias)

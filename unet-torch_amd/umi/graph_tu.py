@@ -259,6 +259,41 @@ class TUTape(Tape):
             self.steps.append(bwd)
         return o
 
+    def qkv_attention(self, a: Act, query, key, value, heads):
+        """softmax(QK^T/sqrt(d))V with the three projections of `a` (reference Attention.forward, vit_seg_modeling.py:73-91)
+        run as ONE GEMM of width 3C: q/k/v are channel slices of one buffer, so the data gradient is one GEMM with
+        K = 3C (no summing of three partial gradients) and the three weight / bias gradients come out of one launch each.
+        The modules stay separate `nn.Linear`s (reference state_dict keys); their weights are concatenated per step."""
+        N, H, W, C = a.shape
+        mods = (query, key, value)
+        wcat = torch.cat([m.weight.detach().float() for m in mods], 0).reshape(3 * C, C, 1, 1)
+        bcat = torch.cat([m.bias.detach().float() for m in mods], 0)
+        qkv = self.alloc(N, H, W, 3 * C, device=a.raw.device)
+        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(wcat, self.dtype, k8=bool(lay)), bcat, qkv, 1, 1, 1, 0)
+        q, k, v = (qkv[..., i * C:(i + 1) * C] for i in range(3))
+        out = self.alloc(N, H, W, C, device=a.raw.device)
+        lse = ops_tu.attn_fwd(q, k, v, out, heads)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                dqkv = self.alloc(N, H, W, 3 * C, device=out.device)
+                ops_tu.attn_bwd(q, k, v, out, o.grad, lse, *(dqkv[..., i * C:(i + 1) * C] for i in range(3)), heads)
+                gw = torch.empty(3 * C, C, dtype=torch.float32, device=out.device)
+                ops.conv_wgrad(a.raw, a.tx, dqkv, None, gw, C, 1, 1, self.inv, 1, 1, 1, 0)
+                gb = torch.empty(3 * C, dtype=torch.float32, device=out.device)
+                ops.colsum(dqkv, gb, self.inv)
+                for i, m in enumerate(mods):
+                    self._set_pgrad(m.weight, gw[i * C:(i + 1) * C])
+                    self._set_pgrad(m.bias, gb[i * C:(i + 1) * C])
+                if _wants_grad(a):
+                    dx = self.alloc(N, H, W, C, device=out.device)
+                    ops.conv_fwd(dqkv, None, lambda lay: ops.pack_conv_dgrad(wcat, self.dtype, k8=bool(lay)), None, dx, 1, 1, 1, 0)
+                    self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
     # ---- decoder -------------------------------------------------------------------------------------------------------
     def bilinear2x_into(self, a: Act, dest):
         """UpsamplingBilinear2d(x2, align_corners=True) of the *activated* `a`, written into `dest` (a channel slice)."""
