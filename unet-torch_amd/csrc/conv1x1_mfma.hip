@@ -47,6 +47,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     constexpr int KPW = BN * 8 / 256;         // 4 or 2
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     __shared__ float4 txbuf[2][CK];          // transform rows of the current / next K chunk, refilled two chunks ahead
+    __shared__ int2 pixinfo[P];              // (image, y << 16 | x) of the tile's pixels on the GEMM grid: computed once in the
+                                             // staging plan, so the epilogue's 16 pieces per thread need no divisions
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
             int n = (int)(m / ((long)geo.h * geo.w));
             int r = (int)(m - (long)n * geo.h * geo.w);
             int yy = r / geo.w, xx = r - yy * geo.w;
+            if (sub == 0) pixinfo[(tid >> 3) + 32 * k] = make_int2(n, (yy << 16) | xx);
             if (GATHER) {
                 nH[k] = n * geo.Hs;
                 by[k] = geo.frac ? yy + geo.pad : yy * geo.stride - geo.pad + geo.soy;
@@ -212,24 +215,31 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
             }
         }
     __syncthreads();
-    constexpr int PPR = BN / 8;
-    for (int i = tid; i < P * PPR; i += 256) {
-        int p = i / PPR, j = i - p * PPR;
-        long m = m0 + p;
-        if (m >= M) continue;
-        int n = (int)(m / ((long)geo.h * geo.w));
-        int r = (int)(m - (long)n * geo.h * geo.w);
-        int yy = r / geo.w, xx = r - yy * geo.w;
-        int cop = c0 + j * 8, co = cop;
+    constexpr int PPR = BN / 8;                 // 16-B pieces per pixel row
+    constexpr int PSTEP = 256 / PPR;            // pixels advanced per trip: the piece column j is fixed per thread
+    {
+        const int j = tid % PPR, p0 = tid / PPR;
+        const int cop = c0 + j * 8;
+        int co = cop, tdy = 0, tdx = 0;
         if (OUT_UPS) {
-            int tap = cop / Nc;
+            const int tap = cop / Nc;
             co = cop - tap * Nc;
-            yy = 2 * yy + (tap >> 1) + geo.doy;
-            xx = 2 * xx + (tap & 1) + geo.dox;
-            if (yy < 0 || yy >= geo.Hd || xx < 0 || xx >= geo.Wd) continue;
+            tdy = (tap >> 1) + geo.doy;
+            tdx = (tap & 1) + geo.dox;
         }
-        uint4 v = *reinterpret_cast<const uint4*>(smem + p * ERS + j * 16);
-        *reinterpret_cast<uint4*>(y + ((long)((long)n * geo.Hd + yy) * geo.Wd + xx) * ldy + co) = v;
+#pragma unroll 4
+        for (int p = p0; p < P; p += PSTEP) {
+            if (m0 + p >= M) break;
+            const int2 pi = pixinfo[p];
+            int yy = pi.y >> 16, xx = pi.y & 0xffff;
+            if (OUT_UPS) {
+                yy = 2 * yy + tdy;
+                xx = 2 * xx + tdx;
+                if (yy < 0 || yy >= geo.Hd || xx < 0 || xx >= geo.Wd) continue;
+            }
+            uint4 v = *reinterpret_cast<const uint4*>(smem + p * ERS + j * 16);
+            *reinterpret_cast<uint4*>(y + ((long)((long)pi.x * geo.Hd + yy) * geo.Wd + xx) * ldy + co) = v;
+        }
     }
 }
 

@@ -742,39 +742,52 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// Same reduction, 4 consecutive output channels per thread (16-B loads of every slab, splits summed in order in registers:
-// no LDS, no barriers); the stores scatter into the parameter's own layout.
+// Same reduction with 16-B slab loads: block = 32 float4 outputs x 8 split lanes (lane l sums splits l, l+8, ... with two
+// independent chains, then the 8 lane sums are added in lane order); the stores scatter into the parameter's own layout.
 __global__ __launch_bounds__(256) void wgrad_reduce_v4_kernel(const float* __restrict__ part, int splits, int RS, int Ci,
                                                               int Co, float* __restrict__ dW, long s_co, long s_ci, long s_t,
                                                               float scale) {
+    __shared__ float4 red[8][33];
     const long total4 = (long)RS * Ci * Co / 4;
     const int Co4 = Co >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-        const float4* p = reinterpret_cast<const float4*>(part) + i;
+    const int ox = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (long base = (long)blockIdx.x * 32; base < total4; base += (long)gridDim.x * 32) {
+        const long i = base + ox;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        int z = 0;
-        for (; z + 1 < splits; z += 2) {                   // two independent chains, fixed order
-            float4 u = p[(long)z * total4], v = p[(long)(z + 1) * total4];
-            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        if (i < total4) {
+            const float4* p = reinterpret_cast<const float4*>(part) + i;
+            int z = sl;
+            for (; z + 8 < splits; z += 16) {
+                float4 u = p[(long)z * total4], v = p[(long)(z + 8) * total4];
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+            }
+            if (z < splits) { float4 u = p[(long)z * total4]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
         }
-        if (z < splits) { float4 u = p[(long)z * total4]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
-        const int co = (int)(i % Co4) * 4;
-        const long rr = i / Co4;
-        const int ci = (int)(rr % Ci), t = (int)(rr / Ci);
-        float* o = dW + ci * s_ci + t * s_t;
-        o[(co + 0) * s_co] = (a.x + b.x) * scale;
-        o[(co + 1) * s_co] = (a.y + b.y) * scale;
-        o[(co + 2) * s_co] = (a.z + b.z) * scale;
-        o[(co + 3) * s_co] = (a.w + b.w) * scale;
+        red[sl][ox] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        __syncthreads();
+        if (sl == 0 && i < total4) {
+            float4 t4 = red[0][ox];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { float4 u = red[k][ox]; t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w; }
+            const int co = (int)(i % Co4) * 4;
+            const long rr = i / Co4;
+            const int ci = (int)(rr % Ci), t = (int)(rr / Ci);
+            float* o = dW + ci * s_ci + t * s_t;
+            o[(co + 0) * s_co] = t4.x * scale;
+            o[(co + 1) * s_co] = t4.y * scale;
+            o[(co + 2) * s_co] = t4.z * scale;
+            o[(co + 3) * s_co] = t4.w * scale;
+        }
+        __syncthreads();
     }
 }
 
 void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
                              long s_t, float scale, hipStream_t st) {
     if (Co % 4 == 0 && (((uintptr_t)part) & 15) == 0) {
-        long g4 = ((long)RS * Ci * Co / 4 + 255) / 256;
-        if (g4 > 8192) g4 = 8192;
+        long g4 = ((long)RS * Ci * Co / 4 + 31) / 32;
+        if (g4 > 16384) g4 = 16384;
         hipLaunchKernelGGL(wgrad_reduce_v4_kernel, dim3((unsigned)g4), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
         return;
     }
