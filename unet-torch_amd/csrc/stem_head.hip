@@ -37,22 +37,57 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const half_t* __restri
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-    for (long p = p0 + pl; p < p0 + STEM_PPB && p < P; p += PL) {
-        int n = (int)(p / ((long)H * W));
-        int r = (int)(p - (long)n * H * W);
-        int yy = r / W, xx = r - yy * W;
+    // every thread walks a contiguous run of pixels: the (image, row, column) cursor advances without divisions and the
+    // 3x3 input window slides (3*CI new values per pixel instead of 9*CI)
+    const int RUN = STEM_PPB / PL;
+    long p = p0 + (long)pl * RUN;
+    long pend = p + RUN;
+    if (pend > P) pend = P;
+    if (pend > p0 + STEM_PPB) pend = p0 + STEM_PPB;
+    int n = 0, yy = 0, xx = 0;
+    if (p < pend) {
+        n = (int)(p / ((long)H * W));
+        const int r = (int)(p - (long)n * H * W);
+        yy = r / W;
+        xx = r - yy * W;
+    }
+    float win[3][3][CI];
+    bool fresh = true;
+    for (; p < pend; ++p) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hi = yy + dy - 1;
+            const bool rowok = hi >= 0 && hi < H;
+            const half_t* xr = x + ((long)((long)n * H + (rowok ? hi : 0)) * W) * ldx;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (!fresh && dx < 2) {
+#pragma unroll
+                    for (int ci = 0; ci < CI; ++ci) win[dy][dx][ci] = win[dy][dx + 1][ci];
+                    continue;
+                }
+                const int wi = xx + dx - 1;
+                const bool ok = rowok && wi >= 0 && wi < W;
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    float v = 0.f;
+                    if (ok) {
+                        v = (float)xr[(long)wi * ldx + ci];
+                        if (tx) v = umi_tx(v, tx[ci]);
+                    }
+                    win[dy][dx][ci] = v;
+                }
+            }
+        }
+        fresh = false;
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            int hi = yy + tap / 3 - 1, wi = xx + tap % 3 - 1;
-            if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
-            const half_t* xp = x + ((long)((long)n * H + hi) * W + wi) * ldx;
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int ci = 0; ci < CI; ++ci) {
-                float v = (float)xp[ci];
-                if (tx) v = umi_tx(v, tx[ci]);
+                const float v = win[tap / 3][tap % 3][ci];
                 const float4* wrow = reinterpret_cast<const float4*>(wsm + (tap * CI + ci) * Co + cg * 8);
                 float4 w0 = wrow[0], w1 = wrow[1];
                 acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]);
@@ -60,7 +95,6 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const half_t* __restri
                 acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]);
                 acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
             }
-        }
         half8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -70,6 +104,11 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const half_t* __restri
             q[j] = fmaf(vr, vr, q[j]);
         }
         *reinterpret_cast<half8*>(y + p * ldy + cg * 8) = o;
+        if (++xx == W) {
+            xx = 0;
+            fresh = true;
+            if (++yy == H) { yy = 0; ++n; }
+        }
     }
     if (part) {
         __syncthreads();
@@ -104,24 +143,54 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const half_t* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
     float4 tc = tx ? tx[ci] : make_float4(0.f, 1.f, 0.f, -INFINITY);
-    for (long p = p0 + pl; p < p0 + WG_PPB && p < P; p += PL) {
-        int n = (int)(p / ((long)H * W));
-        int r = (int)(p - (long)n * H * W);
-        int yy = r / W, xx = r - yy * W;
+    // contiguous run of pixels per thread: division-free cursor, sliding 3x3 window of this input channel
+    const int RUN = WG_PPB / PL;
+    long p = p0 + (long)pl * RUN;
+    long pend = p + RUN;
+    if (pend > P) pend = P;
+    if (pend > p0 + WG_PPB) pend = p0 + WG_PPB;
+    int n = 0, yy = 0, xx = 0;
+    if (p < pend) {
+        n = (int)(p / ((long)H * W));
+        const int r = (int)(p - (long)n * H * W);
+        yy = r / W;
+        xx = r - yy * W;
+    }
+    float win[3][3];
+    bool fresh = true;
+    for (; p < pend; ++p) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hi = yy + dy - 1;
+            const bool rowok = hi >= 0 && hi < H;
+            const half_t* xr = x + ((long)((long)n * H + (rowok ? hi : 0)) * W) * ldx + ci;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (!fresh && dx < 2) { win[dy][dx] = win[dy][dx + 1]; continue; }
+                const int wi = xx + dx - 1;
+                float v = 0.f;
+                if (rowok && wi >= 0 && wi < W) {
+                    v = (float)xr[(long)wi * ldx];
+                    if (tx) v = umi_tx(v, tc);
+                }
+                win[dy][dx] = v;
+            }
+        }
+        fresh = false;
         half8 g = *reinterpret_cast<const half8*>(dy + p * lddy + cg * 8);
         float gf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) gf[j] = (float)g[j];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            int hi = yy + tap / 3 - 1, wi = xx + tap % 3 - 1;
-            float v = 0.f;
-            if (hi >= 0 && hi < H && wi >= 0 && wi < W) {
-                v = (float)x[((long)((long)n * H + hi) * W + wi) * ldx + ci];
-                if (tx) v = umi_tx(v, tc);
-            }
+            const float v = win[tap / 3][tap % 3];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[tap][j] = fmaf(v, gf[j], acc[tap][j]);
+        }
+        if (++xx == W) {
+            xx = 0;
+            fresh = true;
+            if (++yy == H) { yy = 0; ++n; }
         }
     }
     for (int tap = 0; tap < 9; ++tap) {
