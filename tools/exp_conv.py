@@ -7,7 +7,13 @@ import torch
 from umi import build as B
 
 variants = {"base": [], "no_stage": ["-DUMI_EXP_NO_STAGE"], "no_mfma": ["-DUMI_EXP_NO_MFMA"]}
-extra = sys.argv[1:]      # extra -D flags applied to all
+extra = [a for a in sys.argv[1:] if not a.startswith("VAR:")]      # extra -D flags applied to all
+if any(a.startswith("VAR:") for a in sys.argv[1:]):               # VAR:name=-Dflag,-Dflag ... replaces the default variants
+    variants = {"base": []}
+    for a in sys.argv[1:]:
+        if a.startswith("VAR:"):
+            nm, fl = a[4:].split("=", 1)
+            variants[nm] = fl.split(",")
 libs = {}
 for name, flags in variants.items():
     out = os.path.join(REPO, "gpurun_out", f"libexp_{name}.so")
@@ -37,9 +43,9 @@ for nm, n, h, w, ci, co in shapes:
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(20):
             f(*args)
         e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        ms = e0.elapsed_time(e1) / 20
         line.append(f"{name}={ms:.3f}ms({2.0*n*h*w*9*ci*co/ms/1e9:.0f}TF)")
     print("  ".join(line), flush=True)

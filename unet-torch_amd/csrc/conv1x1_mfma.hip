@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
             if (c + 3 < nchunks) txr = UMI_TXROW(c + 3);
         }
         if (c + 1 < nchunks) UMI_ISSUE(c + 1);
+        __builtin_amdgcn_s_setprio(3);              // MFMA phase outranks the other workgroup's staging (see conv_mfma.hip)
 #pragma unroll
         for (int ks = 0; ks < CK / 16; ++ks) {
             half8 af[2], bf[NT];
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
 #undef UMI_ISSUE

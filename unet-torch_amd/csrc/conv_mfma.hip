@@ -216,6 +216,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         if (ci_ + 1 < nchunks) UMI_ISSUE(UMI_CHUNK(ci_ + 1));
 
         // ---- MFMA phase: 9 taps x (2 x 4) tiles -----------------------------------------------
+        // raised wave priority for the MFMA phase: when the two waves of a SIMD compete, the one feeding the matrix pipe wins
+        // over the other workgroup's staging VALU work (measured +3..5 %, +15 % on the 64-channel layers)
+        __builtin_amdgcn_s_setprio(3);
 #ifndef UMI_EXP_NO_MFMA
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             }
         }
 #endif
+        __builtin_amdgcn_s_setprio(0);
 #ifdef UMI_STAMP
         UMI_T(t3);
 #endif

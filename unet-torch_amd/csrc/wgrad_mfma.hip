@@ -436,6 +436,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
     }
 
     // ---------------- consumer waves -------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);                          // the matrix-pipe wave outranks its SIMD's producer wave
     const int wci = wave >> 1, wco = wave & 1;
     floatx16 acc[9];
 #pragma unroll

@@ -16,6 +16,11 @@ _ERR = {-1: "UMI_ERR_BADARG", -2: "UMI_ERR_UNSUPPORTED", -3: "UMI_ERR_WORKSPACE"
 
 
 def _load():
+    alt = os.environ.get("UMI_LIB_OVERRIDE")          # tuning aid: A/B two builds of libunetmi on one box
+    if alt:
+        if not os.path.exists(alt):
+            raise RuntimeError(f"UMI_LIB_OVERRIDE={alt} does not exist")
+        return ctypes.CDLL(alt)
     path = _build.LIB
     if not os.path.exists(path) or (_build.stale() and os.path.exists(_build.HIPCC)):
         if not os.path.exists(_build.HIPCC):
