@@ -182,6 +182,17 @@ int umi_attn_bwd(const void* q, const void* k, const void* v, int ld, const void
 int umi_bilinear2x(const void* x, int ldx, const void* tx, void* y, int ldy, int backward, int N, int H, int W, int C,
                    int dtype, umi_stream_t stream);   /* tx: consumer transform of x, forward only (nullable) */
 
+/* Fused training loss 'dice_bce_mc' (reference loss.py:488-500, DiceLoss loss.py:215-251) on NCHW fp32 logits [N,C,HW],
+ * C <= 8: 0.5 * CrossEntropy + 0.5 * mean_c(1 - (2*sum(p*t)+1e-5)/(sum(p*p)+sum(t*t)+1e-5)), p = softmax(logits).
+ * target [N,HW] class indices; target_dtype 0 = int64, 1 = float32, 2 = uint8, 3 = int32.
+ * fwd fills stats[3*C + 2] = {sum p*t | sum p*p | sum t | CE sum | loss}; bwd writes dlogits = gout[0] * d loss / d logits
+ * (gout: device pointer to the upstream scalar gradient, or NULL for 1). */
+size_t umi_dice_ce_ws_bytes(int N, int C, long HW);
+int umi_dice_ce_fwd(const float* logits, const void* target, int target_dtype, int N, int C, long HW, float* stats, void* ws,
+                    size_t ws_bytes, umi_stream_t stream);
+int umi_dice_ce_bwd(const float* logits, const void* target, int target_dtype, const float* stats, const float* gout, int N,
+                    int C, long HW, float* dlogits, umi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,3 +252,32 @@ def test_conv_transpose_wgrad_mfma(shape):
     scale = ref.abs().max().item()
     assert (res["generic"] - ref).abs().max().item() < 2e-3 * scale
     assert (res["mfma"] - ref).abs().max().item() < 6e-3 * scale
+
+
+@pytest.mark.parametrize("C,tdt", [(2, torch.int64), (4, torch.float32), (3, torch.uint8), (8, torch.int32)])
+def test_fused_dice_ce_loss_matches_composite(C, tdt):
+    """loss.calc_loss('dice_bce_mc') on device logits = two fused kernels per direction; must equal the composite
+    torch formulation of the reference (loss.py:488-500) in value and gradient."""
+    lib, ops = _gpu()
+    import loss as LS
+    g = torch.Generator().manual_seed(C)
+    N, H, W = 3, 37, 29
+    logits = (torch.randn(N, C, H, W, generator=g) * 3).to(DEV).requires_grad_(True)
+    target = torch.randint(0, C, (N, H, W), generator=g).to(tdt).to(DEV)
+    LS.CLASS_NUMBER = C
+    assert LS._fused_ok(logits, target)
+    fused = LS.calc_loss(logits, target, loss_type="dice_bce_mc")
+    (fused * 1.7).backward()
+    gf = logits.grad.clone()
+    ref_in = logits.detach().double().cpu().requires_grad_(True)
+    tl = target.cpu().long()
+    ce = F.cross_entropy(ref_in, tl)
+    p = torch.softmax(ref_in, 1)
+    dice = 0.0
+    for c in range(C):
+        t = (tl == c).double()
+        dice = dice + (1 - (2 * (p[:, c] * t).sum() + 1e-5) / ((p[:, c] ** 2).sum() + (t * t).sum() + 1e-5))
+    ref = 0.5 * ce + 0.5 * dice / C
+    (ref * 1.7).backward()
+    assert abs(fused.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+    assert (gf.cpu().double() - ref_in.grad).abs().max().item() < 2e-5 * ref_in.grad.abs().max().item()

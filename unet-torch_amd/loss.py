@@ -45,8 +45,48 @@ _OUT_OF_SCOPE = {"TopK", "BCE_HEM", "FL", "dice", "dice_bce", "dice_score", "log
                  "HausdorffDTLoss", "HausdorffERLoss", "ActiveContourLoss", "Tversky"}
 
 
+_TARGET_DTYPES = {torch.int64: 0, torch.float32: 1, torch.uint8: 2, torch.int32: 3}
+
+
+class _FusedDiceCE(torch.autograd.Function):
+    """'dice_bce_mc' on device logits as two streaming libunetmi kernels per direction (csrc/loss_kernels.hip) instead of
+    ~25 elementwise / reduction launches; same arithmetic as the composite below (fp64 final sums, deterministic)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        from umi import lib as L, ops
+        N, C = pred.shape[0], pred.shape[1]
+        HW = pred[0, 0].numel()
+        stats = torch.empty(3 * C + 2, dtype=torch.float32, device=pred.device)
+        ws = ops.workspace(L.fn("umi_dice_ce_ws_bytes")(N, C, HW), pred.device)
+        L.check(L.fn("umi_dice_ce_fwd")(pred.data_ptr(), target.data_ptr(), _TARGET_DTYPES[target.dtype], N, C, HW,
+                                        stats.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "umi_dice_ce_fwd")
+        ctx.save_for_backward(pred, target, stats)
+        return stats[3 * C + 1].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        from umi import lib as L, ops
+        pred, target, stats = ctx.saved_tensors
+        N, C = pred.shape[0], pred.shape[1]
+        HW = pred[0, 0].numel()
+        g = gout.detach().to(torch.float32).contiguous()
+        dl = torch.empty_like(pred)
+        L.check(L.fn("umi_dice_ce_bwd")(pred.data_ptr(), target.data_ptr(), _TARGET_DTYPES[target.dtype], stats.data_ptr(),
+                                        g.data_ptr(), N, C, HW, dl.data_ptr(), ops._stream()), "umi_dice_ce_bwd")
+        return dl, None
+
+
+def _fused_ok(pred, target):
+    return (pred.is_cuda and pred.dtype == torch.float32 and pred.dim() >= 3 and pred.is_contiguous() and pred.shape[1] <= 8
+            and pred.shape[1] == CLASS_NUMBER and target.is_cuda and target.is_contiguous() and target.dtype in _TARGET_DTYPES
+            and target.shape[0] == pred.shape[0] and tuple(target.shape[1:]) == tuple(pred.shape[2:]))
+
+
 def calc_loss(pred, target, bce_weight=0.5, loss_type='mse'):
     if loss_type == 'dice_bce_mc':
+        if _fused_ok(pred, target):
+            return _FusedDiceCE.apply(pred, target)
         loss_ce = F.cross_entropy(pred, target.long())
         loss_dice = DiceLoss(CLASS_NUMBER)(pred, target, softmax=True)
         return 0.5 * loss_ce + 0.5 * loss_dice
