@@ -47,6 +47,7 @@ class Tape:
         self.inv = (grad_sink.grad_scale if grad_sink is not None else 1.0) / self.loss_scale
         self.steps = []
         self.param_grads = {}             # id(param) -> (param, grad tensor)
+        self._deferred_unscale = []       # BatchNorm parameter gradients still carrying the loss scale
         self._inputs = []
 
     # ---- helpers -----------------------------------------------------------------------
@@ -133,8 +134,15 @@ class Tape:
                     raise RuntimeError("backward through BatchNorm in eval mode is not supported by the HIP path")
                 inv = self.inv
                 dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd)          # o.grad <- d(raw conv output)
-                self._set_pgrad(bn.weight, dgamma * inv)
-                self._set_pgrad(bn.bias, dbeta * inv)
+                if self.grad_sink is None and inv != 1.0:
+                    # un-scale all BatchNorm parameter gradients with one batched multiply at the end of the backward
+                    # pass (36 tiny launches otherwise); with a gradient sink they must be final before they are handed over
+                    self._deferred_unscale += [dgamma, dbeta]
+                    self._set_pgrad(bn.weight, dgamma)
+                    self._set_pgrad(bn.bias, dbeta)
+                else:
+                    self._set_pgrad(bn.weight, dgamma * inv)
+                    self._set_pgrad(bn.bias, dbeta * inv)
                 gw = self._new_pgrad(weight)
                 ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad)
                 self._set_pgrad(weight, gw)
@@ -274,6 +282,9 @@ class Tape:
         for step in reversed(self.steps):
             step()
         self.steps = []
+        if self._deferred_unscale:
+            torch._foreach_mul_(self._deferred_unscale, self.inv)
+            self._deferred_unscale = []
         if self.grad_sink is not None:
             self.grad_sink.finish()
 
