@@ -72,15 +72,24 @@ __global__ __launch_bounds__(256) void dice_ce_stats_kernel(const float* __restr
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// stats out: [A | B | T | ce_sum | loss]  (3*NC + 2 floats)
-__global__ void dice_ce_finalize_kernel(const float* __restrict__ part, int rows, int NC, long total, float* __restrict__ stats) {
-    __shared__ double sums[3 * 8 + 1];
+// stats out: [A | B | T | ce_sum | loss]  (3*NC + 2 floats).  1,024 threads = 32 columns x 32 row lanes; lane l sums rows
+// l, l+32, ... in fp64, then the 32 lane sums are added in lane order (deterministic).
+__global__ __launch_bounds__(1024) void dice_ce_finalize_kernel(const float* __restrict__ part, int rows, int NC, long total,
+                                                                float* __restrict__ stats) {
+    __shared__ double lanes[32][33];
+    __shared__ double sums[32];
     const int K = 3 * NC + 1;
-    if ((int)threadIdx.x < K) {
-        double s = 0.0;
-        for (int r = 0; r < rows; ++r) s += (double)part[(long)r * K + threadIdx.x];
-        sums[threadIdx.x] = s;
-        stats[threadIdx.x] = (float)s;
+    const int col = threadIdx.x & 31, lane = threadIdx.x >> 5;
+    double s = 0.0;
+    if (col < K)
+        for (int r = lane; r < rows; r += 32) s += (double)part[(long)r * K + col];
+    lanes[lane][col] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int l = 0; l < 32; ++l) t += lanes[l][threadIdx.x];
+        sums[threadIdx.x] = t;
+        if ((int)threadIdx.x < K) stats[threadIdx.x] = (float)t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const float* __restric
 
 int blocks_for(long total) {
     long b = (total + 255) / 256 / 4;                   // ~4 pixels per thread
-    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
 }  // namespace
@@ -154,7 +163,7 @@ extern "C" int umi_dice_ce_fwd(const float* logits, const void* target, int targ
                  case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
 #undef GO
     UMI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, rows, C, total, stats);
+    hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, rows, C, total, stats);
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }
