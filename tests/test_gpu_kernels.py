@@ -281,3 +281,17 @@ def test_fused_dice_ce_loss_matches_composite(C, tdt):
     (ref * 1.7).backward()
     assert abs(fused.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
     assert (gf.cpu().double() - ref_in.grad).abs().max().item() < 2e-5 * ref_in.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("M,C,pad", [(4 * 37 * 29, 2, 0), (2 * 16 * 16, 4, 0), (1001, 2, 0), (4 * 37 * 29, 2, 6), (5000, 64, 0), (777, 768, 0)])
+def test_colsum_paths(M, C, pad):
+    """Bias-gradient column sums: vectorised (C % 8 == 0), folded small-C (dense C in {1,2,4,8}) and scalar fallbacks."""
+    lib, ops = _gpu()
+    g = torch.Generator().manual_seed(M + C)
+    buf = torch.randn(1, 1, M, C + pad, generator=g).half()
+    x = buf[..., :C]
+    ref = x.double().sum((0, 1, 2)) * 0.25
+    out = torch.empty(C, device=DEV)
+    xd = buf.to(DEV)[..., :C]
+    ops.colsum(xd, out, 0.25)
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())

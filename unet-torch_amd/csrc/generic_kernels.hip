@@ -583,6 +583,15 @@ __global__ __launch_bounds__(256) void colsum1_kernel(const T* __restrict__ x, i
     }
 }
 
+__global__ void fold_cols_kernel(const float* __restrict__ tmp8, int C, float* __restrict__ out, float scale) {
+    const int c = threadIdx.x;
+    if (c < C) {
+        float s = 0.f;
+        for (int k = c; k < 8; k += C) s += tmp8[k];
+        out[c] = s * scale;
+    }
+}
+
 static void colsum_plan(long M, int C, int* splits, long* rps) {
     long ctiles = (C + 63) / 64;
     long want = (1024 + ctiles - 1) / ctiles;
@@ -597,7 +606,12 @@ extern "C" size_t umi_colsum_ws_bytes(long M, int C) {
     int splits; long rps;
     colsum_plan(M, C, &splits, &rps);
     const int vrows = umi_colsum_rows_f16v(M, C);
-    return (size_t)(splits > vrows ? splits : vrows) * 2 * (size_t)C * sizeof(float);
+    size_t b = (size_t)(splits > vrows ? splits : vrows) * 2 * (size_t)C * sizeof(float);
+    if (C < 8 && 8 % C == 0 && (M * C) % 8 == 0) {           // the small-C path reads the tensor as rows of 8
+        const size_t b8 = ((size_t)umi_colsum_rows_f16v(M * C / 8, 8) * 2 * 8 + 8) * sizeof(float);
+        if (b8 > b) b = b8;
+    }
+    return b;
 }
 
 extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, long M, int C, int dtype, void* ws,
@@ -613,6 +627,21 @@ extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, l
                            (float*)nullptr, out_scale);
         UMI_LAUNCH_CHECK();
         return UMI_OK;
+    }
+    // a dense tensor with fewer than 8 channels (the n_classes-wide logits gradient): read it as rows of 8 values, sum the 8
+    // interleaved columns with the vectorised kernel, fold column c + C*k into channel c
+    if (dtype == UMI_F16 && C < 8 && 8 % C == 0 && ldx == C && (M * C) % 8 == 0 &&
+        ws_bytes >= ((size_t)umi_colsum_rows_f16v(M * C / 8, 8) * 2 * 8 + 8) * sizeof(float)) {
+        const long M8 = M * C / 8;
+        float* tmp = (float*)ws + (size_t)umi_colsum_rows_f16v(M8, 8) * 2 * 8;
+        if (umi_colsum_f16v(x, 8, (float*)ws, M8, 8, s)) {
+            UMI_LAUNCH_CHECK();
+            hipLaunchKernelGGL(reduce_rows2_kernel, dim3(8), dim3(256), 0, s, (const float*)ws, umi_colsum_rows_f16v(M8, 8), 8, tmp,
+                               (float*)nullptr, 1.f);
+            hipLaunchKernelGGL(fold_cols_kernel, dim3(1), dim3(64), 0, s, (const float*)tmp, C, out, out_scale);
+            UMI_LAUNCH_CHECK();
+            return UMI_OK;
+        }
     }
     dim3 grid((C + 63) / 64, splits);
     if (dtype == UMI_F32) hipLaunchKernelGGL(colsum1_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, (float*)ws, M, C, rps, out, out_scale);
