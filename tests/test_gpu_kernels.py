@@ -283,7 +283,8 @@ def test_fused_dice_ce_loss_matches_composite(C, tdt):
     assert (gf.cpu().double() - ref_in.grad).abs().max().item() < 2e-5 * ref_in.grad.abs().max().item()
 
 
-@pytest.mark.parametrize("M,C,pad", [(4 * 37 * 29, 2, 0), (2 * 16 * 16, 4, 0), (1001, 2, 0), (4 * 37 * 29, 2, 6), (5000, 64, 0), (777, 768, 0)])
+@pytest.mark.parametrize("M,C,pad", [(4 * 37 * 29, 2, 0), (2 * 16 * 16, 4, 0), (1001, 2, 0), (4 * 37 * 29, 2, 6), (5000, 64, 0), (777, 768, 0),
+                                     (300, 3072, 0), (100, 72, 8)])
 def test_colsum_paths(M, C, pad):
     """Bias-gradient column sums: vectorised (C % 8 == 0), folded small-C (dense C in {1,2,4,8}) and scalar fallbacks."""
     lib, ops = _gpu()

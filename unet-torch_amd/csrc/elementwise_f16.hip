@@ -78,35 +78,41 @@ __global__ __launch_bounds__(256) void colsum_v8(const half_t* __restrict__ x, i
                                                  int RPB) {
     __shared__ float red[256][9];
     const int tid = threadIdx.x;
-    const int G = C >> 3, PL = 256 / G;
-    const int cg = tid % G, pl = tid / G;
+    // channel groups of 8: this workgroup covers groups [gb, gb + Gb) (any C % 8 == 0: blockIdx.y walks 256 groups at a time,
+    // a group count that does not divide 256 leaves the tail threads idle)
+    const int Gt = C >> 3, gb = blockIdx.y * 256;
+    const int Gb = Gt - gb < 256 ? Gt - gb : 256;
+    const int PL = 256 / Gb;
+    const int cgl = tid % Gb, pl = tid / Gb, cg = gb + cgl;
     const long r0 = (long)blockIdx.x * RPB;
     long r1 = r0 + RPB;
     if (r1 > M) r1 = M;
     float s0[8], s1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
-    long r = r0 + pl;
-    for (; r + 3 * PL < r1; r += 4 * PL) {         // four independent 16-B loads in flight per thread
-        half8 a = *reinterpret_cast<const half8*>(x + r * ldx + cg * 8);
-        half8 b = *reinterpret_cast<const half8*>(x + (r + PL) * ldx + cg * 8);
-        half8 c = *reinterpret_cast<const half8*>(x + (r + 2 * PL) * ldx + cg * 8);
-        half8 d = *reinterpret_cast<const half8*>(x + (r + 3 * PL) * ldx + cg * 8);
+    if (pl < PL) {
+        long r = r0 + pl;
+        for (; r + 3 * PL < r1; r += 4 * PL) {         // four independent 16-B loads in flight per thread
+            half8 a = *reinterpret_cast<const half8*>(x + r * ldx + cg * 8);
+            half8 b = *reinterpret_cast<const half8*>(x + (r + PL) * ldx + cg * 8);
+            half8 c = *reinterpret_cast<const half8*>(x + (r + 2 * PL) * ldx + cg * 8);
+            half8 d = *reinterpret_cast<const half8*>(x + (r + 3 * PL) * ldx + cg * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s0[j] += (float)a[j] + (float)c[j]; s1[j] += (float)b[j] + (float)d[j]; }
-    }
-    for (; r < r1; r += PL) {
-        half8 a = *reinterpret_cast<const half8*>(x + r * ldx + cg * 8);
+            for (int j = 0; j < 8; ++j) { s0[j] += (float)a[j] + (float)c[j]; s1[j] += (float)b[j] + (float)d[j]; }
+        }
+        for (; r < r1; r += PL) {
+            half8 a = *reinterpret_cast<const half8*>(x + r * ldx + cg * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s0[j] += (float)a[j];
+            for (int j = 0; j < 8; ++j) s0[j] += (float)a[j];
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[tid][j] = s0[j] + s1[j];
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int cl = tid; cl < Gb * 8; cl += 256) {
         float a = 0.f;
-        for (int k = 0; k < PL; ++k) a += red[k * G + (c >> 3)][c & 7];
-        ws[((long)blockIdx.x * 2 + 0) * C + c] = a;
+        for (int k = 0; k < PL; ++k) a += red[k * Gb + (cl >> 3)][cl & 7];
+        ws[((long)blockIdx.x * 2 + 0) * C + gb * 8 + cl] = a;
     }
 }
 
@@ -259,11 +265,20 @@ int grid_for(long items) {
 int umi_bn_bwd_rpb_f16v(long M) { return rpb_for(M); }
 
 // rows of partial sums the vectorised column-sum writes (layout [rows][2][C], slot 0 used), or 0 when it does not apply
-int umi_colsum_rows_f16v(long M, int C) { return (C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0) ? (int)((M + rpb_for(M) - 1) / rpb_for(M)) : 0; }
+// rows per column-sum workgroup: ~1,024 workgroups, at least two rows per pixel lane
+static int rpb_colsum(long M, int C) {
+    const int G = C / 8 < 256 ? C / 8 : 256, PL = 256 / G;
+    long r = (M + 1023) / 1024;
+    if (r < 2 * PL) r = 2 * PL;
+    r = (r + PL - 1) / PL * PL;
+    return (int)(r > 4096 ? 4096 : r);
+}
+int umi_colsum_rows_f16v(long M, int C) { return (C % 8 == 0) ? (int)((M + rpb_colsum(M, C) - 1) / rpb_colsum(M, C)) : 0; }
 bool umi_colsum_f16v(const void* x, int ldx, float* ws, long M, int C, hipStream_t s) {
     if (!umi_colsum_rows_f16v(M, C) || ldx % 8 || !al16(x)) return false;
-    const int rpb = rpb_for(M);
-    hipLaunchKernelGGL(colsum_v8, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, s, (const half_t*)x, ldx, ws, M, C, rpb);
+    const int rpb = rpb_colsum(M, C);
+    hipLaunchKernelGGL(colsum_v8, dim3((unsigned)((M + rpb - 1) / rpb), (C / 8 + 255) / 256), dim3(256), 0, s, (const half_t*)x, ldx, ws,
+                       M, C, rpb);
     return true;
 }
 
