@@ -170,11 +170,19 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # rehearsal knobs for a one-GPU box (not used by the driver): UMI_DDP_BACKEND=gloo + UMI_BENCH_SAME_GPU=1 run N ranks
+    # on device 0 through the same GradReducer / bucket / sink code with gloo carrying the all-reduce
+    backend = os.environ.get("UMI_DDP_BACKEND", "nccl")
+    if os.environ.get("UMI_BENCH_SAME_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import Model
     import loss as L
