@@ -65,14 +65,18 @@ template <bool HAS_TX>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ dy, int lddy,
     float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x, int tiles_y, int tiles_total,
-    int tiles_per_split, int n_co_t) {
+    int tiles_per_split, int n_co_t, int fast_ci) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     __shared__ float4 txs[64];               // this block's 64 transform rows, read from LDS every tile (a global load per
                                              // tile costs ~1.6k cycles of the ~7k-cycle iteration, measured with stamps)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wci = wave >> 1, wco = wave & 1;
-    const int ci0 = (blockIdx.x / n_co_t) * 64, co0 = (blockIdx.x % n_co_t) * 64;
+    // which channel-tile index runs fastest over consecutive workgroup ids (= over the 8 XCDs): with ci fastest every XCD
+    // streams its own input-channel tiles once and all of dy, with co fastest the reverse; the host picks the cheaper one
+    const int n_ci_t = (int)gridDim.x / n_co_t;
+    const int ci0 = (fast_ci ? (int)blockIdx.x % n_ci_t : (int)blockIdx.x / n_co_t) * 64;
+    const int co0 = (fast_ci ? (int)blockIdx.x / n_ci_t : (int)blockIdx.x % n_co_t) * 64;
 #ifdef UMI_STAMP
     UMI_TW(t_start);
     unsigned long long seg[5] = {0, 0, 0, 0, 0};
@@ -278,13 +282,17 @@ template <bool HAS_TX>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ dy, int lddy,
     float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x, int tiles_y, int tiles_total,
-    int tiles_per_split, int n_co_t) {
+    int tiles_per_split, int n_co_t, int fast_ci) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ws[];      // [2][SMEM] then txs[64]
     float4* txs = reinterpret_cast<float4*>(smem_ws + WS_SMEM);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
-    const int ci0 = (blockIdx.x / n_co_t) * 64, co0 = (blockIdx.x % n_co_t) * 64;
+    // which channel-tile index runs fastest over consecutive workgroup ids (= over the 8 XCDs): with ci fastest every XCD
+    // streams its own input-channel tiles once and all of dy, with co fastest the reverse; the host picks the cheaper one
+    const int n_ci_t = (int)gridDim.x / n_co_t;
+    const int ci0 = (fast_ci ? (int)blockIdx.x % n_ci_t : (int)blockIdx.x / n_co_t) * 64;
+    const int co0 = (fast_ci ? (int)blockIdx.x / n_ci_t : (int)blockIdx.x % n_co_t) * 64;
     const int t_begin = blockIdx.y * tiles_per_split;
     int t_end = t_begin + tiles_per_split;
     if (t_end > tiles_total) t_end = tiles_total;
@@ -964,6 +972,10 @@ int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, i
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
     const int n_co_t = (Co + 63) / 64;
     dim3 grid(((Ci + 63) / 64) * n_co_t, splits), block(256);
+    // fabric bytes per pixel tile: x (with its halo, 1.59x) once per XCD that touches a ci tile, dy once per XCD that touches a
+    // co tile: ci fastest costs 1.59 Ci + 8 Co, co fastest 8 * 1.59 Ci + Co
+    static const int force_fast = [] { const char* e = getenv("UMI_WGRAD_FAST_CI"); return e ? atoi(e) : -1; }();
+    const int fast_ci = force_fast >= 0 ? force_fast : (Co < 1.59 * Ci ? 1 : 0);
     static const bool classic = [] { const char* e = getenv("UMI_WGRAD_CLASSIC"); return e && e[0] == '1'; }();
     if (!classic) {
         constexpr int dyn = WS_SMEM + 64 * (int)sizeof(float4);
@@ -976,18 +988,18 @@ int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, i
         dim3 block_ws(512);
         if (txa)
             hipLaunchKernelGGL(wgrad3x3_ws_kernel<true>, grid, block_ws, dyn, s, (const half_t*)x, ldx, (const float4*)txa,
-                               (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t);
+                               (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t, fast_ci);
         else
             hipLaunchKernelGGL(wgrad3x3_ws_kernel<false>, grid, block_ws, dyn, s, (const half_t*)x, ldx, (const float4*)txa,
-                               (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t);
+                               (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t, fast_ci);
     } else if (txa)
         hipLaunchKernelGGL(wgrad3x3_mfma_kernel<true>, grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa,
                            (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps,
-                           n_co_t);
+                           n_co_t, fast_ci);
     else
         hipLaunchKernelGGL(wgrad3x3_mfma_kernel<false>, grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa,
                            (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps,
-                           n_co_t);
+                           n_co_t, fast_ci);
     UMI_LAUNCH_CHECK();
     umi_launch_wgrad_reduce((const float*)ws, splits, 9, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
     UMI_LAUNCH_CHECK();
