@@ -20,12 +20,14 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 // pixels per workgroup tile: template parameter P (256, or 128 when the grid would not fill the chip)
 constexpr int CK = 64;        // K chunk
-constexpr int ROWB = 144;     // LDS row bytes (64 halfs + 16 B pad)
+constexpr int ROWB = 160;     // LDS row bytes: 64 halfs + 32 B pad = 10 slots of 16 B, the stride at which the 16x16x32 fragment
+                              // reads (lane = row l & 15, k group l >> 4) fall on distinct banks in every ds_read_b128 lane group
 
 struct Geo {                  // geometry of the (optionally strided) source / destination tensors
     int h, w;                 // the pixel grid the GEMM's M index runs over (N*h*w pixels)
@@ -91,13 +93,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     const int xl = (tid >> 3) * ROWB + sub * 16;            // + k*32*ROWB
     const int wl = XB + (tid >> 3) * ROWB + sub * 16;       // + k*32*ROWB
 
-    floatx16 acc[2][NT];
+    // v_mfma_f32_16x16x32_f16: per wave 4 channel tiles x 2*NT pixel tiles of 16 x 16 (the register count of the 32x32x16
+    // tiling, the same LDS reads per MAC, half the accumulator traffic per MAC: higher clock under the power cap)
+    floatx4 acc[4][2 * NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+        for (int b = 0; b < 2 * NT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
     half8 xraw[KPX], wraw[KPW];
     half8 zero8;
@@ -136,9 +140,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
             wraw[k] = *reinterpret_cast<const half8*>(wp8 + woff[k] + wadd);                                      \
     } while (0)
 
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    const int b_base = (wm * NT * 32 + lrow) * ROWB + lhalf * 16;         // + nt*32*ROWB + ks*32
-    const int a_base = XB + (wn * 64 + lrow) * ROWB + lhalf * 16;         // + mt*32*ROWB + ks*32
+    const int lrow = lane & 15, lgrp = lane >> 4;
+    const int b_base = (wm * NT * 32 + lrow) * ROWB + lgrp * 16;          // + pt*16*ROWB + ks*64
+    const int a_base = XB + (wn * 64 + lrow) * ROWB + lgrp * 16;          // + ct*16*ROWB + ks*64
 
 #define UMI_TXROW(cc_) (tx[(GATHER ? (cc_) % chunks_per_tap : (cc_)) * CK + tid])
     float4 txr = make_float4(0.f, 1.f, 0.f, 0.f);
@@ -176,17 +180,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         if (c + 1 < nchunks) UMI_ISSUE(c + 1);
         __builtin_amdgcn_s_setprio(3);              // MFMA phase outranks the other workgroup's staging (see conv_mfma.hip)
 #pragma unroll
-        for (int ks = 0; ks < CK / 16; ++ks) {
-            half8 af[2], bf[NT];
+        for (int ks = 0; ks < CK / 32; ++ks) {
+            half8 af[4];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const half8*>(smem + a_base + mt * 32 * ROWB + ks * 32);
+            for (int ct = 0; ct < 4; ++ct) af[ct] = *reinterpret_cast<const half8*>(smem + a_base + ct * 16 * ROWB + ks * 64);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const half8*>(smem + b_base + nt * 32 * ROWB + ks * 32);
+            for (int ph = 0; ph < 2; ++ph) {            // pixel tiles in two halves: 4 + NT fragments live, not 4 + 2*NT
+                half8 bf[NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int i = 0; i < NT; ++i)
+                    bf[i] = *reinterpret_cast<const half8*>(smem + b_base + (ph * NT + i) * 16 * ROWB + ks * 64);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+                        acc[ct][ph * NT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ct], bf[i], acc[ct][ph * NT + i], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
@@ -196,26 +205,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 
     // ---- epilogue: (+bias) -> fp16 -> LDS tile [pixel][BN] -> 16-B stores (scattered per tap for OUT_UPS) -----
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int ct = 0; ct < 4; ++ct) {
+        const int col = wn * 64 + ct * 16 + lgrp * 4;           // accumulator rows = 4 consecutive channels per lane
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int pix = (wm * NT + nt) * 32 + lrow;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = wn * 64 + mt * 32 + g * 8 + lhalf * 4;
-                half4 h;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[mt][nt][g * 4 + j];
-                    if (bias) {
-                        int cop = c0 + col + j;
-                        v += bias[OUT_UPS ? cop % Nc : cop];
-                    }
-                    h[j] = (half_t)v;
-                }
-                *reinterpret_cast<half4*>(smem + pix * ERS + col * 2) = h;
+            for (int j = 0; j < 4; ++j) {
+                const int cop = c0 + col + j;
+                bv[j] = bias[OUT_UPS ? cop % Nc : cop];
             }
         }
+#pragma unroll
+        for (int pt = 0; pt < 2 * NT; ++pt) {
+            const int pix = wm * NT * 32 + pt * 16 + lrow;
+            half4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = (half_t)(acc[ct][pt][j] + bv[j]);
+            *reinterpret_cast<half4*>(smem + pix * ERS + col * 2) = h;
+        }
+    }
     __syncthreads();
     constexpr int PPR = BN / 8;                 // 16-B pieces per pixel row
     constexpr int PSTEP = 256 / PPR;            // pixels advanced per trip: the piece column j is fixed per thread
