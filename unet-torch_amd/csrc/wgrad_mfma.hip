@@ -714,13 +714,17 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
     const int tap_y = GATHER ? (int)blockIdx.z / geo.S : 0, tap_x = GATHER ? (int)blockIdx.z - tap_y * geo.S : 0;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + co0), 0, (int)(M * lddy * 2 - co0 * 2 > 0x7FFFFFF0L ? 0x7FFFFFF0L : M * lddy * 2 - co0 * 2), 0x00020000);
 
-    floatx16 acc[MT][MT];
+    // v_mfma_f32_16x16x32_f16 (K = 32 pixel rows per instruction): 2*MT x 2*MT tiles of 16 x 16 per wave -- the register count
+    // of the 32x32x16 tiling, half its accumulator traffic per MAC (higher clock under the power cap, see wgrad3x3_ws_kernel)
+    constexpr int T16 = 2 * MT;
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    floatx4 acc[T16][T16];
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+    for (int a = 0; a < T16; ++a)
 #pragma unroll
-        for (int b = 0; b < MT; ++b)
+        for (int b = 0; b < T16; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
     half8 xraw[KP], yraw[KP];
     bool xval[KP];
 
@@ -747,9 +751,9 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
     } while (0)
 
     const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
-    const int frag_lane = (8 * (g >> 1) + lq) * PROW + (16 * (g & 1) + 4 * lp) * 2;
-    const unsigned char* a_frag = smem + (wci * MT) * CHB + frag_lane;                  // + mt*CHB + ks*16*PROW
-    const unsigned char* b_frag = smem + NCH * CHB + (wco * MT) * CHB + frag_lane;      // + nt*CHB + ks*16*PROW
+    const int frag_lane = (8 * g + lq) * PROW + (4 * lp) * 2;        // pixel row 8g + lq (+4), channel 4*lp of a 16-channel tile
+    const unsigned char* a_frag = smem + (wci * MT) * CHB + frag_lane;                  // + (t>>1)*CHB + (t&1)*32 + ks*32*PROW
+    const unsigned char* b_frag = smem + NCH * CHB + (wco * MT) * CHB + frag_lane;
 
     if (t_begin < t_end) UMI_ISSUE1(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
@@ -773,30 +777,30 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
         __syncthreads();
         if (tile + 1 < t_end) UMI_ISSUE1(tile + 1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            half8 af[MT], bf[MT];
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 af[T16], bf[T16];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = tr_frag(a_frag + mt * CHB + ks * 16 * PROW);
+            for (int t = 0; t < T16; ++t) af[t] = tr_frag(a_frag + (t >> 1) * CHB + (t & 1) * 32 + ks * 32 * PROW);
 #pragma unroll
-            for (int nt = 0; nt < MT; ++nt) bf[nt] = tr_frag(b_frag + nt * CHB + ks * 16 * PROW);
+            for (int t = 0; t < T16; ++t) bf[t] = tr_frag(b_frag + (t >> 1) * CHB + (t & 1) * 32 + ks * 32 * PROW);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int ta = 0; ta < T16; ++ta)
 #pragma unroll
-                for (int nt = 0; nt < MT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+                for (int tb = 0; tb < T16; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
         }
         __syncthreads();
     }
 #undef UMI_ISSUE1
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int ta = 0; ta < T16; ++ta)
 #pragma unroll
-        for (int nt = 0; nt < MT; ++nt) {
-            const int co = co0 + (wco * MT + nt) * 32 + (lane & 31);
+        for (int tb = 0; tb < T16; ++tb) {
+            const int co = co0 + (wco * T16 + tb) * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int ci = ci0 + (wci * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                part[(((long)blockIdx.y * gridDim.z + blockIdx.z) * Ci + ci) * Co + co] = acc[mt][nt][r];
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + (wci * T16 + ta) * 16 + 4 * (lane >> 4) + r;
+                part[(((long)blockIdx.y * gridDim.z + blockIdx.z) * Ci + ci) * Co + co] = acc[ta][tb][r];
             }
         }
 }
