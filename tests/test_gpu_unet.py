@@ -291,3 +291,47 @@ def test_grad_reducer_sink_path_matches_plain_backward():
     for p, g in zip(m.parameters(), plain):
         assert torch.equal(p.grad, g)
         assert torch.equal(red.buffer_for(p), g)
+
+
+def test_dropout_kernel_with_consumer_transform_and_unet_dropout_mode():
+    """U-Net `dropout=True` (reference Model.py:34-41,59-61,79-83): the dropout kernel applies the producer's lazy BN+ReLU,
+    scales the kept values by 1/(1-p) and its backward reuses the mask; the network trains with it and ignores it in eval."""
+    _need_gpu()
+    from umi import ops_tu
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C, p = 2, 9, 7, 16, 0.3
+    for dt in (torch.float16, torch.float32):
+        x = torch.randn(N, H, W, C, generator=g).to(dt).to(DEV)
+        tx = torch.stack([torch.zeros(C), torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2, torch.zeros(C)], 1)
+        y = torch.empty_like(x)
+        mask = torch.empty(x.numel(), dtype=torch.uint8, device=DEV)
+        ops_tu.dropout(x, y, mask, False, p, 1234, tx.to(DEV).contiguous())
+        act = torch.relu(x.float().cpu() * tx[:, 1] + tx[:, 2])
+        keep = mask.cpu().view(N, H, W, C).bool()
+        exp = torch.where(keep, act / (1 - p), torch.zeros(()))
+        assert (y.float().cpu() - exp).abs().max().item() <= 2e-3 * exp.abs().max().item()
+        assert 0.55 < keep.float().mean().item() < 0.85
+        gy = torch.randn(N, H, W, C, generator=g).to(dt).to(DEV)
+        dx = torch.empty_like(gy)
+        ops_tu.dropout(gy, dx, mask, True, p, 0)
+        exp_dx = torch.where(keep, gy.float().cpu() / (1 - p), torch.zeros(()))
+        assert (dx.float().cpu() - exp_dx).abs().max().item() <= 2e-3 * exp_dx.abs().max().item()
+    import Model
+    torch.manual_seed(11)
+    m = Model.UNet(1, 2, 8, True, True, 0.25, compute_dtype="fp16").to(DEV)
+    assert "down1.maxpool_conv.2.double_conv.0.weight" in m.state_dict()        # reference key layout with dropout=True
+    xin = torch.randn(2, 1, 32, 32, device=DEV)
+    m.train()
+    torch.manual_seed(1)
+    a = m(xin)
+    a.square().mean().backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in m.parameters())
+    torch.manual_seed(1)
+    b = m(xin)
+    torch.manual_seed(2)
+    c = m(xin)
+    assert torch.equal(a, b) and not torch.equal(a, c)          # seeded by torch's generator
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(xin), m(xin)
+    assert torch.equal(e1, e2)

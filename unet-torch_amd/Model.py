@@ -100,24 +100,21 @@ def _build_double_conv(t, a, dc, out=None):
     return t.conv_bn(y1, seq[3].weight, seq[4], out=out)
 
 
-def _check_dropout(mod, flag):
-    if flag and mod.training:
-        raise NotImplementedError(
-            "dropout=True in training mode is not implemented by the HIP path yet (reference default is "
-            "dropout=False, Model.py:96); eval mode is supported")
-
-
 def _build_down(t, a, down, out=None):
-    _check_dropout(down, down.dropout)
-    return _build_double_conv(t, t.pool2(a), down.maxpool_conv[-1], out=out)
+    p = t.pool2(a)
+    if down.dropout:                               # MaxPool2d -> Dropout(p) -> DoubleConv (reference Model.py:34-41)
+        p = t.dropout(p, down.maxpool_conv[1].p)
+    return _build_double_conv(t, p, down.maxpool_conv[-1], out=out)
 
 
 def _build_up(t, x1, skip, cat, up):
     """`skip` already lives in cat[..., :C]; the transposed conv fills cat[..., C:]."""
-    _check_dropout(up, up.dropout_flag)
     C = skip.shape[3]
     u = t.conv_transpose2x2(x1, up.up.weight, up.up.bias, cat[..., C:])
-    return _build_double_conv(t, t.concat(cat, [skip, u]), up.conv)
+    c = t.concat(cat, [skip, u])
+    if up.dropout_flag:                            # cat -> Dropout(p) -> DoubleConv (reference Model.py:79-83)
+        c = t.dropout(c, up.dropout.p)
+    return _build_double_conv(t, c, up.conv)
 
 
 class DoubleConv(_UmiModule):

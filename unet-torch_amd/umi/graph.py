@@ -252,6 +252,29 @@ class Tape:
             self.steps.append(bwd)
         return o
 
+    def dropout(self, a: Act, p):
+        """nn.Dropout(p) of the *activated* `a` (reference Model.py:37 after the max-pool, :80-81 after the concat).  The
+        consumer transform of `a`, if any, is applied inside the kernel; the result is stored activated.  Mask from the
+        library's own counter-based stream, seeded from torch's CPU generator (so torch.manual_seed reproduces a run)."""
+        if not self.training or p <= 0.0:
+            return a
+        from . import ops_tu
+        N, H, W, C = a.shape
+        out = self.alloc(N, H, W, C, device=a.raw.device)
+        mask = torch.empty(N * H * W * C, dtype=torch.uint8, device=a.raw.device)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        ops_tu.dropout(a.raw, out, mask, False, p, seed, a.tx)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None or not _wants_grad(a):
+                    return
+                dx = self.alloc(N, H, W, C, device=out.device)
+                ops_tu.dropout(o.grad, dx, mask, True, p, 0)
+                self._give(a, dx)
+            self.steps.append(bwd)
+        return o
+
     def concat(self, buf, acts):
         """`acts` were produced into consecutive channel slices of `buf`."""
         txs, parts, c0 = [], [], 0

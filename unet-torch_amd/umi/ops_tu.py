@@ -111,10 +111,10 @@ def add_bcast(a, rows_tensor, y, bcast_rows):
     elementwise(3, a, rows_tensor, y, bcast_rows)
 
 
-def dropout(x, y, mask, backward, p, seed):
+def dropout(x, y, mask, backward, p, seed, tx=None):
     M, C, ldx = _rows(x)
     L.check(L.fn("umi_dropout")(x.data_ptr(), ldx, y.data_ptr(), _rows(y)[2], mask.data_ptr(), int(backward), p,
-                                seed & 0xFFFFFFFF, M, C, _dt(x), _stream()), "umi_dropout")
+                                seed & 0xFFFFFFFF, M, C, _dt(x), _ptr(tx), _stream()), "umi_dropout")
 
 
 def attn_fwd(q, k, v, o, heads):
