@@ -107,6 +107,16 @@ int umi_bn_bwd_apply(void* da, int ldda, const void* y, int ldy, const void* tx,
                      const float* rstd, const float* sum_dz, const float* sum_dzx,
                      long M, int C, int dtype, umi_stream_t stream);
 
+/* Fusion of the two previous steps for a DoubleConv's inner layer (reference Model.py:15-22): the 3x3 data gradient that
+ * produces `da` = d(activated output) of a BatchNorm+ReLU layer also emits stage 1 of that layer's reduction
+ * (`ybn`/`txbn`/`rstd` = that layer's raw output, transform and 1/std): part[rows][2][Co] per-tile sums of dz and
+ * dz*xhat, rows = umi_conv_fwd_plan(...)'s stat_rows.  umi_bn_bwd_from_partials finishes the reduction; umi_bn_bwd_apply
+ * follows as usual.  Returns UMI_ERR_UNSUPPORTED off the MFMA path (caller falls back to the separate calls). */
+int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, void* da, int ldda, const void* ybn, int ldybn,
+                         const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
+                         int dtype, umi_stream_t stream);
+int umi_bn_bwd_from_partials(const float* part, int rows, int C, float* sum_dz, float* sum_dzx, umi_stream_t stream);
+
 /* Weight gradient of umi_conv_fwd (autograd of the reference convs):
  *   dW[co*s_co + ci*s_ci + t*s_t] = out_scale * sum_{n,ho,wo} txa(x[...,ci]) * txb(dy[n,ho,wo,co])
  * fp32 output in the parameter's own layout (OIHW: s_co=Ci*R*S, s_ci=R*S, s_t=1).

@@ -293,6 +293,46 @@ def test_grad_reducer_sink_path_matches_plain_backward():
         assert torch.equal(red.buffer_for(p), g)
 
 
+def test_fused_dgrad_bn_reduction_matches_separate_kernels(monkeypatch):
+    """DoubleConv's second conv: its data-gradient kernel also produces stage 1 of the first layer's BatchNorm backward
+    reduction (umi_conv_dgrad_bnred).  Gradients must agree with the separate-kernel path (same values, other sum order)."""
+    _need_gpu()
+    import Model
+    torch.manual_seed(4)
+    m = Model.UNet(1, 2, 64, compute_dtype="fp16").to(DEV).train()
+    x = torch.randn(2, 1, 96, 64, device=DEV)
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UMI_NO_BNRED_FUSION", mode)
+        m.zero_grad()
+        m(x).square().mean().backward()
+        grads[mode] = [p.grad.clone() for p in m.parameters()]
+    # the two paths add the same fp32 terms in a different order; a last-bit change of a channel sum flips fp16 roundings
+    # of that layer's dz, which later layers see as ~1e-3 relative noise (measured 1.6e-3 worst)
+    worst = max(rel_err(a, b) for a, b in zip(grads["0"], grads["1"]))
+    assert worst < 5e-3, worst
+    # kernel level, odd sizes (partial tiles): the fused epilogue's sums == the stand-alone reduction's, to fp32 accuracy
+    from umi import ops
+    g = torch.Generator().manual_seed(9)
+    N, H, W, Ci, Co = 2, 21, 37, 64, 128                 # data gradient: dy has Ci channels, da has Co
+    dy = torch.randn(N, H, W, Ci, generator=g).half().to(DEV)
+    ybn = torch.randn(N, H, W, Co, generator=g).half().to(DEV)
+    wt = (torch.randn(Ci, Co, 3, 3, generator=g) * 0.05).to(DEV)     # forward conv Co -> Ci, so its dgrad maps Ci -> Co
+    tx = torch.stack([torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2,
+                      torch.zeros(Co)], 1).contiguous().to(DEV)
+    rstd = (torch.rand(Co, generator=g) + 0.5).to(DEV)
+    da1, da2 = (torch.empty(N, H, W, Co, device=DEV, dtype=torch.float16) for _ in range(2))
+    wp = ops.pack_conv_dgrad(wt, torch.float16, k8=True)
+    part = ops.conv_dgrad_bnred(dy, wp, da1, ybn, tx, rstd)
+    assert part is not None
+    ops.conv_fwd(dy, None, lambda l: wp, None, da2, 3, 3, 1, 1)
+    assert torch.equal(da1, da2)
+    s_f = ops.bn_bwd(da1, ybn, tx, rstd, partials=part)
+    s_r = ops.bn_bwd(da2, ybn, tx, rstd)
+    for a, b in zip(s_f, s_r):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
 def test_dropout_kernel_with_consumer_transform_and_unet_dropout_mode():
     """U-Net `dropout=True` (reference Model.py:34-41,59-61,79-83): the dropout kernel applies the producer's lazy BN+ReLU,
     scales the kept values by 1/(1-p) and its backward reuses the mask; the network trains with it and ignores it in eval."""

@@ -97,7 +97,7 @@ class _UmiModule(nn.Module):
 def _build_double_conv(t, a, dc, out=None):
     seq = dc.double_conv
     y1 = t.conv_bn(a, seq[0].weight, seq[1])
-    return t.conv_bn(y1, seq[3].weight, seq[4], out=out)
+    return t.conv_bn(y1, seq[3].weight, seq[4], out=out, input_exclusive=True)    # y1 has no other consumer
 
 
 def _build_down(t, a, down, out=None):

@@ -110,6 +110,33 @@ extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int
     return UMI_OK;
 }
 
+int umi_conv3x3_mfma_bnred(const void* dy, int lddy, const void* wp8, void* da, int ldda, const void* ybn, int ldybn,
+                           const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
+                           hipStream_t s);
+void umi_launch_reduce_rows2(const float* ws, int rows, int C, float* out0, float* out1, float scale, hipStream_t s);
+
+// 3x3 / stride 1 / pad 1 data gradient (x = dy, Ci = the forward conv's Co, weights rotated + transposed as for umi_conv_fwd)
+// fused with stage 1 of the BatchNorm+ReLU backward of the layer whose activated output the gradient belongs to:
+// part[rows][2][Co] <- per-tile sums of dz and dz*xhat (rows = umi_conv_fwd_plan's stat_rows for this problem).
+// UMI_ERR_UNSUPPORTED when the shape is not on the MFMA path: the caller then runs the separate kernels.
+extern "C" int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, void* da, int ldda, const void* ybn, int ldybn,
+                                    const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
+                                    int dtype, umi_stream_t stream) {
+    if (!dy || !wp8 || !da || !ybn || !txbn || !rstd || !part || N <= 0 || H <= 0 || W <= 0) return UMI_ERR_BADARG;
+    if (!umi_conv3x3_mfma_ok(N, H, W, Ci, Co, 3, 3, 1, 1, H, W, lddy, ldda, dtype, dtype, 0, nullptr) || ldybn % 8 || ldybn < Co)
+        return UMI_ERR_UNSUPPORTED;
+    if (((uintptr_t)dy | (uintptr_t)da | (uintptr_t)wp8 | (uintptr_t)ybn) & 15) return UMI_ERR_BADARG;
+    return umi_conv3x3_mfma_bnred(dy, lddy, wp8, da, ldda, ybn, ldybn, txbn, rstd, part, N, H, W, Ci, Co, (hipStream_t)stream);
+}
+
+// stage 2 of the BatchNorm backward reduction on partial rows produced by umi_conv_dgrad_bnred
+extern "C" int umi_bn_bwd_from_partials(const float* part, int rows, int C, float* sum_dz, float* sum_dzx, umi_stream_t stream) {
+    if (!part || !sum_dz || !sum_dzx || rows <= 0 || C <= 0) return UMI_ERR_BADARG;
+    umi_launch_reduce_rows2(part, rows, C, sum_dz, sum_dzx, 1.f, (hipStream_t)stream);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
 // UMI_TRACE_GENERIC=1: report every conv that lands on the generic (non-MFMA) kernels -- a tuning aid, off by default
 static bool trace_generic() {
     static const bool on = [] { const char* e = getenv("UMI_TRACE_GENERIC"); return e && e[0] == '1'; }();

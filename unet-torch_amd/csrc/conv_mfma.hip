@@ -65,11 +65,18 @@ struct Cfg {
     static constexpr int KPW = (NPW + 255) / 256;
 };
 
-template <int TH, int BN, bool HAS_TX, bool STATS>
+// Epilogue reductions written as one partial row per pixel tile, part[tile][2][Co]:
+//   EPI 1: sum / sum of squares of the stored outputs (BatchNorm statistics of THIS conv's output, forward);
+//   EPI 2: this launch is the data gradient that produces d(activated output) of a BatchNorm+ReLU layer whose raw output
+//          is `bn.y`: sum dz and sum dz*xhat of that layer (dz = stored value * [tx(y) > lo]), i.e. stage 1 of its
+//          BatchNorm backward without re-reading the gradient tensor.
+struct BnRed { const half_t* y; int ld; const float4* tx; const float* rstd; };
+
+template <int TH, int BN, bool HAS_TX, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     half_t* __restrict__ y, int ldy, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x,
-    int tiles_y, int n_co, int xcd_chunk) {
+    int tiles_y, int n_co, int xcd_chunk, BnRed bn) {
     using C = Cfg<TH, BN>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];
     // consumer-transform rows of the current / next chunk (16 channels x float4), refilled two chunks ahead so the
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         }
     }
 
-    if (STATS) {
+    if (EPI) {
         // column sums from the LDS tile, 8 channels (one 16-B read) per thread per pixel: thread = (col group, pixel slice)
         constexpr int CG = BN / 8;                  // column groups (16 or 8)
         constexpr int SL = 256 / CG;                // pixel slices (16 or 32)
@@ -301,13 +308,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         float s[8], s2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = s2[j] = 0.f;
+        if (EPI == 1) {
 #pragma unroll 4
-        for (int k = 0; k < PPS; ++k) {
-            const int p = sl * PPS + k;
-            if (full_tile || (ty0 + (p >> 5) < H && tx0 + (p & 31) < W)) {
-                half8 v = *reinterpret_cast<const half8*>(smem + p * C::ERS + cg * 16);
+            for (int k = 0; k < PPS; ++k) {
+                const int p = sl * PPS + k;
+                if (full_tile || (ty0 + (p >> 5) < H && tx0 + (p & 31) < W)) {
+                    half8 v = *reinterpret_cast<const half8*>(smem + p * C::ERS + cg * 16);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; s2[j] = fmaf(f, f, s2[j]); }
+                    for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; s2[j] = fmaf(f, f, s2[j]); }
+                }
+            }
+        } else if (cg * 8 < cvalid) {
+            float4 t[8];
+            float rs_[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { t[j] = bn.tx[c0 + cg * 8 + j]; rs_[j] = bn.rstd[c0 + cg * 8 + j]; }
+            const half_t* yb = bn.y + ((long)((long)n * H + ty0) * W + tx0) * bn.ld + c0 + cg * 8;
+#pragma unroll 4
+            for (int k = 0; k < PPS; ++k) {
+                const int p = sl * PPS + k;
+                const int row = p >> 5, col = p & 31;
+                if (full_tile || (ty0 + row < H && tx0 + col < W)) {
+                    half8 v = *reinterpret_cast<const half8*>(smem + p * C::ERS + cg * 16);
+                    half8 yv = *reinterpret_cast<const half8*>(yb + ((long)row * W + col) * bn.ld);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float yy = (float)yv[j];
+                        const float dz = umi_tx_pre(yy, t[j]) > t[j].w ? (float)v[j] : 0.f;
+                        s[j] += dz;
+                        s2[j] = fmaf(dz, (yy - t[j].x) * rs_[j], s2[j]);
+                    }
+                }
             }
         }
         __syncthreads();                            // every thread is done with the tile: reuse it for the slice sums
@@ -340,18 +371,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 
 template <int TH, int BN>
 int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H, int W,
-           int Ci, int Co, hipStream_t s) {
+           int Ci, int Co, const BnRed* bnred, hipStream_t s) {
     const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = (Co + BN - 1) / BN;
     const long nblk = (long)N * tiles_x * tiles_y * n_co;
     dim3 grid((unsigned)nblk), block(256);
     static const bool xcd_off = [] { const char* e = getenv("UMI_CONV_NO_XCD_ORDER"); return e && e[0] == '1'; }();
     const int xcd_chunk = (n_co > 1 && !xcd_off) ? (int)(nblk / 8) : 0;     // ids beyond 8 * chunk (the remainder) keep their order
-#define GO(HT, ST)                                                                                               \
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, ST>), grid, block, 0, s, (const half_t*)x, ldx,          \
+    const BnRed bn = bnred ? *bnred : BnRed{nullptr, 0, nullptr, nullptr};
+#define GO(HT, EP)                                                                                               \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, EP>), grid, block, 0, s, (const half_t*)x, ldx,          \
                        (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
-                       tiles_y, n_co, xcd_chunk)
-    if (tx) { if (part) GO(true, true); else GO(true, false); }
-    else    { if (part) GO(false, true); else GO(false, false); }
+                       tiles_y, n_co, xcd_chunk, bn)
+    if (bnred) { if (tx) GO(true, 2); else GO(false, 2); }
+    else if (tx) { if (part) GO(true, 1); else GO(true, 0); }
+    else    { if (part) GO(false, 1); else GO(false, 0); }
 #undef GO
     UMI_LAUNCH_CHECK();
     return UMI_OK;
@@ -386,6 +419,15 @@ int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Co) {
 
 int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
                      int N, int H, int W, int Ci, int Co, hipStream_t s) {
-    if (use_bn128(Co)) return launch<8, 128>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, s);
-    return launch<16, 64>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, s);
+    if (use_bn128(Co)) return launch<8, 128>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, s);
+    return launch<16, 64>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, s);
+}
+
+// data gradient + stage 1 of the BatchNorm backward of the layer whose activated-output gradient it produces (EPI 2)
+int umi_conv3x3_mfma_bnred(const void* dy, int lddy, const void* wp8, void* da, int ldda, const void* ybn, int ldybn,
+                           const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
+                           hipStream_t s) {
+    const BnRed bn{(const half_t*)ybn, ldybn, (const float4*)txbn, rstd};
+    if (use_bn128(Co)) return launch<8, 128>(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, &bn, s);
+    return launch<16, 64>(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, &bn, s);
 }

@@ -13,19 +13,28 @@ parameter gradients are produced in fp32, unscaled, in the parameter's own layou
 Reference semantics implemented here: Model.py:7-26 (DoubleConv), :29-47 (Down),
 :50-83 (Up), :86-92 (OutConv); BatchNorm2d train/eval behaviour as torch.nn.
 """
+import os
+
 import torch
 
 from . import lib as L
 from . import ops
 
 
+def _fuse_bnred():
+    return os.environ.get("UMI_NO_BNRED_FUSION") != "1"          # tuning / A-B knob, read per call
+
+
 class Act:
     """Lazily-activated NHWC tensor.  `raw` is an [N,H,W,C] view, `tx` the consumer transform
     (None = consume as stored).  `grad` = d loss / d activated value (same layout/dtype)."""
-    __slots__ = ("raw", "tx", "grad", "parts", "needs_grad")
+    __slots__ = ("raw", "tx", "grad", "parts", "needs_grad", "bn_rstd", "bn_part")
 
     def __init__(self, raw, tx=None, parts=None, needs_grad=True):
         self.raw, self.tx, self.grad, self.parts, self.needs_grad = raw, tx, None, parts, needs_grad
+        self.bn_rstd = None       # conv_bn outputs: 1/std of the batch statistics (BatchNorm backward)
+        self.bn_part = None       # stage-1 partial sums of this layer's BatchNorm backward, when its only consumer's
+                                  # data-gradient kernel produced them (conv_bn(..., input_exclusive=True))
 
     @property
     def shape(self):
@@ -105,8 +114,10 @@ class Tape:
         return a
 
     # ---- ops ---------------------------------------------------------------------------
-    def conv_bn(self, a: Act, weight, bn, out=None, stride=1, pad=1):
-        """Conv2d(bias=False) -> BatchNorm2d -> ReLU, the last two deferred to the consumer."""
+    def conv_bn(self, a: Act, weight, bn, out=None, stride=1, pad=1, input_exclusive=False):
+        """Conv2d(bias=False) -> BatchNorm2d -> ReLU, the last two deferred to the consumer.
+        input_exclusive: this conv is the ONLY consumer of `a` (DoubleConv's second conv): its data-gradient kernel may then
+        also emit stage 1 of `a`'s BatchNorm backward reduction (one pass over the gradient tensor less)."""
         Co, Ci, R, S = weight.shape
         N, H, W, Ca = a.shape
         assert Ca == Ci, f"conv expects {Ci} input channels, got {Ca}"
@@ -126,6 +137,7 @@ class Tape:
         else:
             tx, rstd = ops.eval_bn_tx(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
         o = Act(out, tx)
+        o.bn_rstd = rstd
         if self.record:
             def bwd():
                 if o.grad is None:
@@ -133,7 +145,8 @@ class Tape:
                 if not self.training:
                     raise RuntimeError("backward through BatchNorm in eval mode is not supported by the HIP path")
                 inv = self.inv
-                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd)          # o.grad <- d(raw conv output)
+                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd, partials=o.bn_part)   # o.grad <- d(raw conv output)
+                o.bn_part = None
                 if self.grad_sink is None and inv != 1.0:
                     # un-scale all BatchNorm parameter gradients with one batched multiply at the end of the backward
                     # pass (36 tiny launches otherwise); with a gradient sink they must be final before they are handed over
@@ -150,8 +163,16 @@ class Tape:
                     if stride != 1:
                         raise NotImplementedError("dgrad for strided conv_bn")
                     dx = self.alloc(N, H, W, Ci, device=out.device)
-                    ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(wf, self.dtype, k8=bool(lay)), None, dx,
-                                 R, S, 1, R - 1 - pad)
+                    part = None
+                    if (input_exclusive and _fuse_bnred() and a.grad is None and a.parts is None and a.bn_rstd is not None
+                            and a.tx is not None and (R, S, pad) == (3, 3, 1) and self.dtype == torch.float16):
+                        part = ops.conv_dgrad_bnred(o.grad, ops.pack_conv_dgrad(wf, self.dtype, k8=True), dx, a.raw, a.tx,
+                                                    a.bn_rstd)
+                    if part is not None:
+                        a.bn_part = part
+                    else:
+                        ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(wf, self.dtype, k8=bool(lay)), None, dx,
+                                     R, S, 1, R - 1 - pad)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o

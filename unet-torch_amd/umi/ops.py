@@ -186,17 +186,41 @@ def workspace(nbytes, device):
     return buf
 
 
-def bn_bwd(da, y, tx, rstd):
-    """In place: da <- dy.  Returns (sum_dz, sum_dzx) = (d beta, d gamma) (still loss-scaled)."""
+def conv_dgrad_bnred(dy, wp8, da, ybn, txbn, rstd):
+    """3x3 data gradient da <- conv(dy, rotated weights) that also emits stage 1 of the BatchNorm backward reduction of the
+    layer whose raw output is `ybn` (the layer `da` belongs to).  Returns the partial-sum tensor, or None when the shape
+    is not on the MFMA path (nothing was launched)."""
+    N, H, W, Ci, lddy = _nhwc(dy)
+    _, _, _, Co, ldda = _nhwc(da)
+    ldybn = _nhwc(ybn)[4]
+    lay, rows = conv_plan(dy, da, 3, 3, 1, 1)
+    if lay != 1:
+        return None
+    part = torch.empty(rows * 2 * Co, dtype=torch.float32, device=dy.device)
+    st = L.fn("umi_conv_dgrad_bnred")(dy.data_ptr(), lddy, wp8.data_ptr(), da.data_ptr(), ldda, ybn.data_ptr(), ldybn,
+                                      txbn.data_ptr(), rstd.data_ptr(), part.data_ptr(), N, H, W, Ci, Co, _dt(dy), _stream())
+    if st == -2:
+        return None
+    L.check(st, "umi_conv_dgrad_bnred")
+    return part
+
+
+def bn_bwd(da, y, tx, rstd, partials=None):
+    """In place: da <- dy.  Returns (sum_dz, sum_dzx) = (d beta, d gamma) (still loss-scaled).  `partials`: stage-1 rows
+    already produced by conv_dgrad_bnred for this layer (the reduction pass over `da` is skipped)."""
     N, H, W, C, ldy = _nhwc(y)
     _, _, _, _, ldda = _nhwc(da)
     M = N * H * W
     nb = L.fn("umi_bn_bwd_ws_bytes")(M, C)
     ws = workspace(nb, y.device)
     sums = torch.empty(2, C, dtype=torch.float32, device=y.device)
-    L.check(L.fn("umi_bn_bwd_reduce")(da.data_ptr(), ldda, y.data_ptr(), ldy, tx.data_ptr(), rstd.data_ptr(),
-                                      sums[0].data_ptr(), sums[1].data_ptr(), M, C, _dt(y), ws.data_ptr(),
-                                      ws.numel(), _stream()), "umi_bn_bwd_reduce")
+    if partials is not None:
+        L.check(L.fn("umi_bn_bwd_from_partials")(partials.data_ptr(), partials.numel() // (2 * C), C, sums[0].data_ptr(),
+                                                 sums[1].data_ptr(), _stream()), "umi_bn_bwd_from_partials")
+    else:
+        L.check(L.fn("umi_bn_bwd_reduce")(da.data_ptr(), ldda, y.data_ptr(), ldy, tx.data_ptr(), rstd.data_ptr(),
+                                          sums[0].data_ptr(), sums[1].data_ptr(), M, C, _dt(y), ws.data_ptr(),
+                                          ws.numel(), _stream()), "umi_bn_bwd_reduce")
     L.check(L.fn("umi_bn_bwd_apply")(da.data_ptr(), ldda, y.data_ptr(), ldy, tx.data_ptr(), rstd.data_ptr(),
                                      sums[0].data_ptr(), sums[1].data_ptr(), M, C, _dt(y), _stream()),
             "umi_bn_bwd_apply")
