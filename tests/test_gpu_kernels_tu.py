@@ -253,3 +253,40 @@ def test_root_conv_and_seg_head_narrow_kernels():
             dW = torch.empty(ncls, Ci, 3, 3, device=DEV)
             ops.conv_wgrad(xd, tx.to(DEV), gld, None, dW, Ci * 9, 9, 1, 1.0, 3, 3, 1, 1, flags=flags)
             _close(dW, wr.grad, 3e-3)
+
+
+def test_bilinear_pool_gn_fp16_vector_paths():
+    """fp16 (16-B vectorised) variants of bilinear x2 (+ consumer transform) and its adjoint, and GroupNorm with fewer than 8
+    channels per group (ResNetV2 root / first block: 64 channels, 32 groups)."""
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(31)
+    xb = torch.randn(2, 5, 7, 24, generator=g).half()
+    t = torch.zeros(24, 4); t[:, 1] = 1.5; t[:, 2] = 0.1
+    act = torch.clamp_min(xb.float() * 1.5 + 0.1, 0.0).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ub = F.interpolate(act, scale_factor=2, mode="bilinear", align_corners=True)
+    gb = torch.randn(ub.shape, generator=g).half()
+    ub.backward(gb.float())
+    yb = torch.empty(2, 10, 14, 24, device=DEV, dtype=torch.float16)
+    T.bilinear2x(xb.to(DEV), yb, False, t.to(DEV))
+    _close(yb.permute(0, 3, 1, 2), ub, 2e-3)
+    dxb = torch.empty(2, 5, 7, 24, device=DEV, dtype=torch.float16)
+    T.bilinear2x(gb.permute(0, 2, 3, 1).contiguous().to(DEV), dxb, True)
+    _close(dxb.permute(0, 3, 1, 2), act.grad, 3e-3)
+    # GroupNorm, 2 channels per group
+    N, H, W, C, G = 2, 9, 11, 64, 32
+    x = (torch.randn(N, H, W, C, generator=g) * 2 + 0.5).half()
+    gamma, beta = 0.5 + torch.rand(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy = torch.randn(N, H, W, C, generator=g).half()
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.relu(F.group_norm(xr, G, gr, br, 1e-6))
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    y = torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+    xd = x.to(DEV)
+    mean, rstd = T.gn_fwd(xd, gamma.to(DEV), beta.to(DEV), G, 1e-6, True, None, y)
+    _close(y.permute(0, 3, 1, 2), ref, 4e-3)
+    dx = torch.empty_like(y)
+    dg, db = T.gn_bwd(dy.to(DEV), y, xd, mean, rstd, gamma.to(DEV), G, True, dx, None, 1.0)
+    _close(dx.permute(0, 3, 1, 2), xr.grad, 4e-2)
+    _close(dg, gr.grad, 2e-2)
+    _close(db, br.grad, 2e-2)

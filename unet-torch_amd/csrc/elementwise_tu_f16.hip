@@ -173,6 +173,8 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const half_t* __restrict
 }
 
 // GroupNorm apply / backward apply, 8 channels per thread (all 8 in one group: Cg % 8 == 0)
+// UNI: the 8 channels of a thread lie in one group (Cg % 8 == 0); otherwise every channel looks up its own group
+template <bool UNI>
 __global__ __launch_bounds__(256) void gn_apply8_kernel(const half_t* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const half_t* __restrict__ res, int ldr,
@@ -183,8 +185,13 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const half_t* __restrict
         const int c = (int)(i % C8) * 8;
         const long p = i / C8;
         const int n = (int)(p / HW);
-        const int sg = n * G + c / Cg;
-        const float m = mean[sg], r = rstd[sg];
+        float m[8], r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int sg = n * G + (c + (UNI ? 0 : j)) / Cg;
+            m[j] = mean[sg];
+            r[j] = rstd[sg];
+        }
         half8 xv = *reinterpret_cast<const half8*>(x + p * ldx + c), rv, o;
         if (res) rv = *reinterpret_cast<const half8*>(res + p * ldr + c);
         const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const half_t* __restrict
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = ((float)xv[j] - m) * r * gg[j] + bb[j];
+            float v = ((float)xv[j] - m[j]) * r[j] * gg[j] + bb[j];
             if (res) v += (float)rv[j];
             if (relu) v = fmaxf(v, 0.f);
             o[j] = (half_t)v;
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const half_t* __restrict
     }
 }
 
+template <bool UNI>
 __global__ __launch_bounds__(256) void gn_bwd_apply8_kernel(const half_t* __restrict__ dy, int lddy, const half_t* __restrict__ y,
                                                             int ldy, const half_t* __restrict__ x, int ldx,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -214,8 +222,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply8_kernel(const half_t* __rest
         const int c = (int)(i % C8) * 8;
         const long p = i / C8;
         const int n = (int)(p / HW);
-        const int sg = n * G + c / Cg;
-        const float m = mean[sg], r = rstd[sg], q1 = gsum[sg * 2 + 0] * invm, q2 = gsum[sg * 2 + 1] * invm;
+        float m[8], r[8], q1[8], q2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int sg = n * G + (c + (UNI ? 0 : j)) / Cg;
+            m[j] = mean[sg];
+            r[j] = rstd[sg];
+            q1[j] = gsum[sg * 2 + 0] * invm;
+            q2[j] = gsum[sg * 2 + 1] * invm;
+        }
         half8 gv = *reinterpret_cast<const half8*>(dy + p * lddy + c);
         half8 xv = *reinterpret_cast<const half8*>(x + p * ldx + c), yv, o, dz8;
         if (relu) yv = *reinterpret_cast<const half8*>(y + p * ldy + c);
@@ -225,8 +240,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply8_kernel(const half_t* __rest
         for (int j = 0; j < 8; ++j) {
             float dz = (float)gv[j];
             if (relu && !((float)yv[j] > 0.f)) dz = 0.f;
-            const float xh = ((float)xv[j] - m) * r;
-            o[j] = (half_t)(r * (dz * gg[j] - q1 - xh * q2));
+            const float xh = ((float)xv[j] - m[j]) * r[j];
+            o[j] = (half_t)(r[j] * (dz * gg[j] - q1[j] - xh * q2[j]));
             dz8[j] = (half_t)dz;
         }
         *reinterpret_cast<half8*>(dx + p * lddx + c) = o;
@@ -278,26 +293,130 @@ bool umi_ln_bwd_f16v(const void* dy, int lddy, const void* x, int ldx, const flo
     return true;
 }
 
+// ---- UpsamplingBilinear2d(x2, align_corners=True) forward / adjoint, 8 channels per thread (same per-element float
+// expressions as the scalar kernels in transformer_kernels.hip) ------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void bilinear2x_fwd8_kernel(const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx,
+                                                              half_t* __restrict__ y, int ldy, int N, int H, int W, int C8) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long total = (long)N * Ho * Wo * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long p = i / C8;
+        const int wo = (int)(p % Wo);
+        const long r = p / Wo;
+        const int ho = (int)(r % Ho), n = (int)(r / Ho);
+        const float fy = ho * sy, fx = wo * sx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+        const float ly = fy - y0, lx = fx - x0;
+        const half_t* b = x + (long)n * H * W * ldx + c;
+        const half8 a00 = *reinterpret_cast<const half8*>(b + ((long)y0 * W + x0) * ldx);
+        const half8 a01 = *reinterpret_cast<const half8*>(b + ((long)y0 * W + x1) * ldx);
+        const half8 a10 = *reinterpret_cast<const half8*>(b + ((long)y1 * W + x0) * ldx);
+        const half8 a11 = *reinterpret_cast<const half8*>(b + ((long)y1 * W + x1) * ldx);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v00 = (float)a00[j], v01 = (float)a01[j], v10 = (float)a10[j], v11 = (float)a11[j];
+            if (tx) { const float4 t = tx[c + j]; v00 = umi_tx(v00, t); v01 = umi_tx(v01, t); v10 = umi_tx(v10, t); v11 = umi_tx(v11, t); }
+            o[j] = (half_t)((1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11));
+        }
+        *reinterpret_cast<half8*>(y + p * ldy + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bilinear2x_bwd8_kernel(const half_t* __restrict__ dy, int lddy, half_t* __restrict__ dx,
+                                                              int lddx, int N, int H, int W, int C8) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long total = (long)N * H * W * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long p = i / C8;
+        const int w = (int)(p % W);
+        const long r = p / W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        int ho_lo = sy > 0.f ? (int)floorf((h - 1) / sy) : 0, ho_hi = sy > 0.f ? (int)ceilf((h + 1) / sy) : Ho - 1;
+        int wo_lo = sx > 0.f ? (int)floorf((w - 1) / sx) : 0, wo_hi = sx > 0.f ? (int)ceilf((w + 1) / sx) : Wo - 1;
+        ho_lo = ho_lo < 0 ? 0 : ho_lo; wo_lo = wo_lo < 0 ? 0 : wo_lo;
+        ho_hi = ho_hi > Ho - 1 ? Ho - 1 : ho_hi; wo_hi = wo_hi > Wo - 1 ? Wo - 1 : wo_hi;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            const float fy = ho * sy;
+            const int y0 = (int)fy;
+            const int y1 = y0 + 1 < H ? y0 + 1 : H - 1;
+            const float ly = fy - y0;
+            const float wy = (y0 == h ? 1.f - ly : 0.f) + (y1 == h ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const float fx = wo * sx;
+                const int x0 = (int)fx;
+                const int x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+                const float lx = fx - x0;
+                const float wx = (x0 == w ? 1.f - lx : 0.f) + (x1 == w ? lx : 0.f);
+                if (wx == 0.f) continue;
+                const half8 g = *reinterpret_cast<const half8*>(dy + ((long)((long)n * Ho + ho) * Wo + wo) * lddy + c);
+                const float ww = wy * wx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(ww, (float)g[j], acc[j]);
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+        *reinterpret_cast<half8*>(dx + p * lddx + c) = o;
+    }
+}
+
+}  // namespace
+
+bool umi_bilinear2x_f16v(const void* x, int ldx, const void* tx, void* y, int ldy, int backward, int N, int H, int W, int C,
+                         hipStream_t s) {
+    if (C % 8 || ldx % 8 || ldy % 8 || !al16(x) || !al16(y)) return false;
+    const int C8 = C / 8;
+    if (!backward)
+        hipLaunchKernelGGL(bilinear2x_fwd8_kernel, dim3(grid8((long)N * 4 * H * W * C8)), dim3(256), 0, s, (const half_t*)x, ldx,
+                           (const float4*)tx, (half_t*)y, ldy, N, H, W, C8);
+    else
+        hipLaunchKernelGGL(bilinear2x_bwd8_kernel, dim3(grid8((long)N * H * W * C8)), dim3(256), 0, s, (const half_t*)x, ldx,
+                           (half_t*)y, ldy, N, H, W, C8);
+    return true;
+}
+
 bool umi_gn_apply_f16v(const void* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        const void* res, int ldr, void* y, int ldy, int relu, int N, long HW, int C, int G, hipStream_t s) {
-    if (C % G || (C / G) % 8 || ldx % 8 || ldy % 8 || (res && ldr % 8) || !al16(x) || !al16(y) || (res && !al16(res)) ||
+    if (C % G || C % 8 || ldx % 8 || ldy % 8 || (res && ldr % 8) || !al16(x) || !al16(y) || (res && !al16(res)) ||
         !al16(gamma) || !al16(beta))
         return false;
     const int C8 = C / 8;
-    hipLaunchKernelGGL(gn_apply8_kernel, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd, gamma,
-                       beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C8, G, C / G);
+    if ((C / G) % 8 == 0)
+        hipLaunchKernelGGL(gn_apply8_kernel<true>, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd,
+                           gamma, beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C8, G, C / G);
+    else
+        hipLaunchKernelGGL(gn_apply8_kernel<false>, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd,
+                           gamma, beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C8, G, C / G);
     return true;
 }
 
 bool umi_gn_bwd_apply_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                            const float* rstd, const float* gamma, const float* gsum, int relu, void* dx, int lddx, void* dres,
                            int lddr, int N, long HW, int C, int G, hipStream_t s) {
-    if (C % G || (C / G) % 8 || lddy % 8 || ldy % 8 || ldx % 8 || lddx % 8 || (dres && lddr % 8) || !al16(dy) || !al16(y) ||
+    if (C % G || C % 8 || lddy % 8 || ldy % 8 || ldx % 8 || lddx % 8 || (dres && lddr % 8) || !al16(dy) || !al16(y) ||
         !al16(x) || !al16(dx) || (dres && !al16(dres)) || !al16(gamma))
         return false;
     const int C8 = C / 8;
-    hipLaunchKernelGGL(gn_bwd_apply8_kernel, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)dy, lddy,
-                       (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx,
-                       (half_t*)dres, lddr, N, HW, C8, G, C / G);
+    if ((C / G) % 8 == 0)
+        hipLaunchKernelGGL(gn_bwd_apply8_kernel<true>, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)dy, lddy,
+                           (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx,
+                           (half_t*)dres, lddr, N, HW, C8, G, C / G);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply8_kernel<false>, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)dy, lddy,
+                           (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx,
+                           (half_t*)dres, lddr, N, HW, C8, G, C / G);
     return true;
 }

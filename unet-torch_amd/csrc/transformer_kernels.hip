@@ -563,6 +563,8 @@ bool umi_gn_apply_f16v(const void* x, int ldx, const float* mean, const float* r
 bool umi_gn_bwd_apply_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                            const float* rstd, const float* gamma, const float* gsum, int relu, void* dx, int lddx, void* dres,
                            int lddr, int N, long HW, int C, int G, hipStream_t s);
+bool umi_bilinear2x_f16v(const void* x, int ldx, const void* tx, void* y, int ldy, int backward, int N, int H, int W, int C,
+                         hipStream_t s);
 // attention_mfma.hip
 bool umi_attn_mfma_ok(int D, int ld, int ldo, int dtype, const void* a, const void* b, const void* c);
 int umi_attn_fwd_mfma(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse, int B, int N, int Hh,
@@ -803,6 +805,10 @@ extern "C" int umi_bilinear2x(const void* x, int ldx, const void* tx, void* y, i
     // forward: x [N,H,W,C] -> y [N,2H,2W,C];  backward: x = dy [N,2H,2W,C] -> y = dx [N,H,W,C]
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return UMI_ERR_BADARG;
     hipStream_t s = (hipStream_t)st;
+    if (dtype == UMI_F16 && umi_bilinear2x_f16v(x, ldx, tx, y, ldy, backward, N, H, W, C, s)) {
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     if (!backward) {
         const int grid = grid_for((long)N * 4 * H * W * C);
         DT_SWITCH(dtype,
