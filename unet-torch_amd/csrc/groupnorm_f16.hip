@@ -8,14 +8,20 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int ROWS = 512;        // pixel rows per stage-1 workgroup
+// pixel rows per stage-1 workgroup: ~1,024 workgroups per launch (a fixed 512 left the 14x14 / 28x28 stages of the
+// ResNet with one workgroup per sample: 24 of 256 CUs busy)
+static int gn_rows(int N, long HW) {
+    long r = ((long)N * HW + 1023) / 1024;
+    r = (r + 7) / 8 * 8;
+    return (int)(r < 16 ? 16 : (r > 512 ? 512 : r));
+}
 
 // MODE 0: out = (sum x, sum x^2) per channel.   MODE 1: out = (sum dz*xhat, sum dz) per channel, dz = dy*[y>0 | 1]
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_rowsum_v8(const half_t* __restrict__ x, int ldx, const half_t* __restrict__ dy,
                                                     int lddy, const half_t* __restrict__ y, int ldy,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
-                                                    long HW, int C, int G, int S, float* __restrict__ ws) {
+                                                    long HW, int C, int G, int S, float* __restrict__ ws, int ROWS) {
     __shared__ float red[2][256][9];
     const int tid = threadIdx.x;
     const int G8 = C >> 3, PL = 256 / G8;
@@ -118,15 +124,15 @@ bool shape_ok(int C, int G) {
 
 }  // namespace
 
-int umi_gn_splits(long HW) { return (int)((HW + ROWS - 1) / ROWS); }
+int umi_gn_splits(int N, long HW) { const int r = gn_rows(N, HW); return (int)((HW + r - 1) / r); }
 
 // returns false when the shape does not qualify (caller falls back to the generic kernels)
 bool umi_gn_stats_f16v(const void* x, int ldx, int N, long HW, int C, int G, float eps, float* mean, float* rstd, float* ws,
                        hipStream_t s) {
     if (!shape_ok(C, G) || ldx % 8 || !al16(x)) return false;
-    const int S = umi_gn_splits(HW);
+    const int S = umi_gn_splits(N, HW);
     hipLaunchKernelGGL(gn_rowsum_v8<0>, dim3(N, S), dim3(256), 0, s, (const half_t*)x, ldx, (const half_t*)nullptr, 0,
-                       (const half_t*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0, HW, C, G, S, ws);
+                       (const half_t*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0, HW, C, G, S, ws, gn_rows(N, HW));
     hipLaunchKernelGGL(gn_stats_finalize, dim3((N * G + 255) / 256), dim3(256), 0, s, (const float*)ws, N, S, C, G, HW, eps,
                        mean, rstd);
     return true;
@@ -137,9 +143,9 @@ bool umi_gn_bwd_reduce_f16v(const void* dy, int lddy, const void* y, int ldy, co
                             const float* rstd, const float* gamma, int relu, int N, long HW, int C, int G, float* gsum,
                             float* part, float* ws, hipStream_t s) {
     if (!shape_ok(C, G) || ldx % 8 || lddy % 8 || ldy % 8 || !al16(x) || !al16(dy) || !al16(y)) return false;
-    const int S = umi_gn_splits(HW);
+    const int S = umi_gn_splits(N, HW);
     hipLaunchKernelGGL(gn_rowsum_v8<1>, dim3(N, S), dim3(256), 0, s, (const half_t*)x, ldx, (const half_t*)dy, lddy,
-                       (const half_t*)y, ldy, mean, rstd, relu, HW, C, G, S, ws);
+                       (const half_t*)y, ldy, mean, rstd, relu, HW, C, G, S, ws, gn_rows(N, HW));
     const long np = (long)N * 2 * C;
     hipLaunchKernelGGL(gn_bwd_part, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const float*)ws, N, S, C, part);
     hipLaunchKernelGGL(gn_bwd_gsum, dim3((N * G + 255) / 256), dim3(256), 0, s, (const float*)part, gamma, N, C, G, gsum);

@@ -544,7 +544,7 @@ __global__ void bilinear2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __r
 
 void umi_launch_reduce_rows2(const float* ws, int rows, int C, float* out0, float* out1, float scale, hipStream_t s);
 // groupnorm_f16.hip
-int umi_gn_splits(long HW);
+int umi_gn_splits(int N, long HW);
 bool umi_gn_stats_f16v(const void* x, int ldx, int N, long HW, int C, int G, float eps, float* mean, float* rstd, float* ws,
                        hipStream_t s);
 bool umi_gn_bwd_reduce_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
@@ -591,7 +591,7 @@ extern "C" int umi_wstd_bwd(const float* wstd, const float* rstd, const float* g
     return UMI_OK;
 }
 
-extern "C" size_t umi_gn_fwd_ws_bytes(int N, long HW, int C) { return (size_t)N * umi_gn_splits(HW) * 2 * C * sizeof(float); }
+extern "C" size_t umi_gn_fwd_ws_bytes(int N, long HW, int C) { return (size_t)N * umi_gn_splits(N, HW) * 2 * C * sizeof(float); }
 
 extern "C" int umi_gn_fwd(const void* x, int ldx, const float* gamma, const float* beta, const void* res, int ldr, void* y,
                           int ldy, float* mean, float* rstd, int relu, int N, long HW, int C, int G, float eps, int dtype,
@@ -619,7 +619,7 @@ extern "C" int umi_gn_fwd(const void* x, int ldx, const float* gamma, const floa
 }
 
 extern "C" size_t umi_gn_bwd_ws_bytes(int N, long HW, int C, int G) {
-    return ((size_t)N * G * 2 + (size_t)N * 2 * C + (size_t)N * umi_gn_splits(HW) * 2 * C) * sizeof(float);
+    return ((size_t)N * G * 2 + (size_t)N * 2 * C + (size_t)N * umi_gn_splits(N, HW) * 2 * C) * sizeof(float);
 }
 
 extern "C" int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
