@@ -73,15 +73,19 @@ __global__ __launch_bounds__(256) void gn_rowsum_v8(const half_t* __restrict__ x
 // forward stage 2: one thread per (sample, group): fp64 combine over splits and the group's channels
 __global__ void gn_stats_finalize(const float* __restrict__ ws, int N, int S, int C, int G, long HW, float eps,
                                   float* __restrict__ mean, float* __restrict__ rstd) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per (sample, group): lanes stride over the S x Cg partial sums (fixed assignment), butterfly in fp64
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= N * G) return;
     const int n = i / G, g = i % G, Cg = C / G;
     double s = 0.0, q = 0.0;
-    for (int sp = 0; sp < S; ++sp)
-        for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
-            s += (double)ws[(((long)n * S + sp) * 2 + 0) * C + c];
-            q += (double)ws[(((long)n * S + sp) * 2 + 1) * C + c];
-        }
+    for (int k = lane; k < S * Cg; k += 64) {
+        const int sp = k / Cg, c = g * Cg + (k - sp * Cg);
+        s += (double)ws[(((long)n * S + sp) * 2 + 0) * C + c];
+        q += (double)ws[(((long)n * S + sp) * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane) return;
     const double cnt = (double)HW * Cg;
     const double m = s / cnt;
     double var = q / cnt - m * m;
@@ -133,7 +137,7 @@ bool umi_gn_stats_f16v(const void* x, int ldx, int N, long HW, int C, int G, flo
     const int S = umi_gn_splits(N, HW);
     hipLaunchKernelGGL(gn_rowsum_v8<0>, dim3(N, S), dim3(256), 0, s, (const half_t*)x, ldx, (const half_t*)nullptr, 0,
                        (const half_t*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0, HW, C, G, S, ws, gn_rows(N, HW));
-    hipLaunchKernelGGL(gn_stats_finalize, dim3((N * G + 255) / 256), dim3(256), 0, s, (const float*)ws, N, S, C, G, HW, eps,
+    hipLaunchKernelGGL(gn_stats_finalize, dim3((N * G + 3) / 4), dim3(256), 0, s, (const float*)ws, N, S, C, G, HW, eps,
                        mean, rstd);
     return true;
 }
