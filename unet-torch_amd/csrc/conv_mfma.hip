@@ -284,63 +284,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     constexpr int PSTEP = 256 / PPR;                // pixels advanced per k (16 or 32)
     constexpr int NK = C::P / PSTEP;                // 16
     const bool full_tile = (ty0 + TH <= H) && (tx0 + 32 <= W);
+    // The same pass feeds the epilogue reductions (EPI): a thread keeps one 8-channel column group j for all its pixels, so
+    // the per-channel sums accumulate in registers from the values it is storing anyway (no second LDS pass).
+    constexpr int CG = PPR;                         // column groups (16 or 8)
+    constexpr int SL = PSTEP;                       // pixel slices = threads per column group (16 or 32)
+    const int cg = tid % PPR, sl = tid / PPR;
+    float s[8], s2[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) s[jj] = s2[jj] = 0.f;
     {
-        const int j = tid % PPR, p0 = tid / PPR;
+        const int j = cg, p0 = sl;
         half_t* ybase = y + ((long)((long)n * H + ty0) * W + tx0) * ldy + c0 + j * 8;
         const unsigned char* sbase = smem + p0 * C::ERS + j * 16;
+        const bool col_ok = j * 8 < cvalid;
+        float4 t[8];
+        float rs_[8];
+        const half_t* yb = nullptr;
+        if (EPI == 2 && col_ok) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) { t[jj] = bn.tx[c0 + j * 8 + jj]; rs_[jj] = bn.rstd[c0 + j * 8 + jj]; }
+            yb = bn.y + ((long)((long)n * H + ty0) * W + tx0) * bn.ld + c0 + j * 8;
+        }
 #pragma unroll 8
         for (int k = 0; k < NK; ++k) {
             const int p = p0 + k * PSTEP;
             const int row = p >> 5, col = p & 31;
-            if (j * 8 < cvalid && (full_tile || (ty0 + row < H && tx0 + col < W))) {
+            if (col_ok && (full_tile || (ty0 + row < H && tx0 + col < W))) {
                 uint4 v = *reinterpret_cast<const uint4*>(sbase + k * PSTEP * C::ERS);
                 *reinterpret_cast<uint4*>(ybase + ((long)row * W + col) * ldy) = v;
+                if (EPI == 1) {
+                    const half8 hv = __builtin_bit_cast(half8, v);
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) { float f = (float)hv[jj]; s[jj] += f; s2[jj] = fmaf(f, f, s2[jj]); }
+                } else if (EPI == 2) {
+                    const half8 hv = __builtin_bit_cast(half8, v);
+                    const half8 yv = *reinterpret_cast<const half8*>(yb + ((long)row * W + col) * bn.ld);
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const float yy = (float)yv[jj];
+                        const float dz = umi_tx_pre(yy, t[jj]) > t[jj].w ? (float)hv[jj] : 0.f;
+                        s[jj] += dz;
+                        s2[jj] = fmaf(dz, (yy - t[jj].x) * rs_[jj], s2[jj]);
+                    }
+                }
             }
         }
     }
 
     if (EPI) {
-        // column sums from the LDS tile, 8 channels (one 16-B read) per thread per pixel: thread = (col group, pixel slice)
-        constexpr int CG = BN / 8;                  // column groups (16 or 8)
-        constexpr int SL = 256 / CG;                // pixel slices (16 or 32)
-        constexpr int PPS = C::P / SL;              // pixels per slice (16)
-        const int cg = tid % CG, sl = tid / CG;
-        float s[8], s2[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = s2[j] = 0.f;
-        if (EPI == 1) {
-#pragma unroll 4
-            for (int k = 0; k < PPS; ++k) {
-                const int p = sl * PPS + k;
-                if (full_tile || (ty0 + (p >> 5) < H && tx0 + (p & 31) < W)) {
-                    half8 v = *reinterpret_cast<const half8*>(smem + p * C::ERS + cg * 16);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; s2[j] = fmaf(f, f, s2[j]); }
-                }
-            }
-        } else if (cg * 8 < cvalid) {
-            float4 t[8];
-            float rs_[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { t[j] = bn.tx[c0 + cg * 8 + j]; rs_[j] = bn.rstd[c0 + cg * 8 + j]; }
-            const half_t* yb = bn.y + ((long)((long)n * H + ty0) * W + tx0) * bn.ld + c0 + cg * 8;
-#pragma unroll 4
-            for (int k = 0; k < PPS; ++k) {
-                const int p = sl * PPS + k;
-                const int row = p >> 5, col = p & 31;
-                if (full_tile || (ty0 + row < H && tx0 + col < W)) {
-                    half8 v = *reinterpret_cast<const half8*>(smem + p * C::ERS + cg * 16);
-                    half8 yv = *reinterpret_cast<const half8*>(yb + ((long)row * W + col) * bn.ld);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float yy = (float)yv[j];
-                        const float dz = umi_tx_pre(yy, t[j]) > t[j].w ? (float)v[j] : 0.f;
-                        s[j] += dz;
-                        s2[j] = fmaf(dz, (yy - t[j].x) * rs_[j], s2[j]);
-                    }
-                }
-            }
-        }
         __syncthreads();                            // every thread is done with the tile: reuse it for the slice sums
         float* rs = reinterpret_cast<float*>(smem);         // [2][SL][BN]
 #pragma unroll
