@@ -174,14 +174,20 @@ def pool2_bwd(dpool, x, tx, da, accumulate):
 
 
 _ws_cache = {}
+_ws_high = {}          # device -> largest workspace requested so far
+_ws_pinned = []        # blocks referenced by captured graphs
 
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per device+stream (split-K slabs, reduction partials)."""
     key = (device, torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
+    need = max(int(nbytes), _ws_high.get(device, 1 << 20))
+    _ws_high[device] = need                     # a new stream (e.g. a graph-capture stream) starts at the size already seen
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None and torch.cuda.is_current_stream_capturing():
+            _ws_pinned.append(buf)              # kernels already captured into a HIP graph keep pointing at the old block
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 
