@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured HIP graph (umi.graphs.GraphedStep; single GPU only, opt-in)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,8 +210,22 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(a.warmup):
-        step()
+    graphed = None
+    if a.graph and world == 1:
+        from umi.graphs import GraphedStep
+
+        def step_xy(xx, yy):
+            logits = model(xx)
+            loss = L.calc_loss(logits, yy, loss_type="dice_bce_mc")
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+        graphed = GraphedStep(step_xy, [x, labels], warmup=max(1, a.warmup))     # warm-up steps run eagerly on a side stream
+        step = lambda: graphed(x, labels)                                        # noqa: E731
+    else:
+        for _ in range(a.warmup):
+            step()
 
     def fence():
         torch.cuda.synchronize()
@@ -240,7 +256,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": f"UNet({a.cin},{a.ncls},{a.features}) train step (fwd + dice_bce_mc + bwd + SGD), "
                                    f"{a.size}x{a.size}, batch {a.batch}/GPU, BASELINE configs[1]",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": "hipgraph" if graphed is not None else "eager",
                        "algorithmic_tflops_per_gpu": round(3 * gf * a.batch * a.steps / dt / 1e3, 2)},
             "final_loss": round(final_loss, 5),
         }

@@ -177,9 +177,10 @@ int umi_elementwise(int mode, const void* x, int ldx, const void* g, int ldg, vo
 
 /* Dropout (vit_seg_modeling.py:103,151; U-Net Down / Up, Model.py:37,80-81): forward writes a byte mask (own counter-based
  * RNG stream) and y = keep ? tx(x) / (1-p) : 0 (tx: nullable consumer transform of x, forward only); backward (x = dy)
- * reuses the mask. */
+ * reuses the mask.  seed_dev (nullable): device counter added into the stream seed inside the kernel, so a step replayed
+ * from a captured HIP graph still draws a fresh mask every replay. */
 int umi_dropout(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
-                int dtype, const void* tx, umi_stream_t stream);
+                int dtype, const void* tx, const unsigned* seed_dev, umi_stream_t stream);
 
 /* Multi-head softmax attention (vit_seg_modeling.py:73-91): q,k,v,o are [B, N, heads*D] token tensors (row stride ld),
  * head h = channels [h*D, (h+1)*D); softmax(q k^T / sqrt(D)) v.  lse/delta: [B*heads*N] fp32 scratch kept for backward. */

@@ -333,6 +333,18 @@ def test_fused_dgrad_bn_reduction_matches_separate_kernels(monkeypatch):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
 
 
+def test_graphed_step_matches_eager_trajectory():
+    """umi.graphs.GraphedStep: a training step captured in a HIP graph and replayed must follow the eager trajectory
+    (same kernels, same order: bit-identical losses and weights).  Runs in a child process: stream capture is sensitive to
+    autograd state left by earlier eager steps of the same process, and a runtime crash must not take the suite down."""
+    _need_gpu()
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_graphed_step.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "GRAPHED_STEP_OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_dropout_kernel_with_consumer_transform_and_unet_dropout_mode():
     """U-Net `dropout=True` (reference Model.py:34-41,59-61,79-83): the dropout kernel applies the producer's lazy BN+ReLU,
     scales the kept values by 1/(1-p) and its backward reuses the mask; the network trains with it and ignores it in eval."""

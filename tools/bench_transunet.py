@@ -23,7 +23,12 @@ x = torch.randn(B, 1, size, size, device="cuda")
 lab = torch.randint(0, 2, (B, size, size), device="cuda").float()
 def step():
     out = m(x); l = L.calc_loss(out, lab, loss_type="dice_bce_mc"); opt.zero_grad(); l.backward(); opt.step(); return l
-for _ in range(2): step()
+if os.environ.get("UMI_BENCH_GRAPH") == "1":
+    from umi.graphs import GraphedStep
+    gs = GraphedStep(lambda xx, yy: step(), [x, lab], warmup=2)      # x / lab are the static buffers themselves
+    step = lambda: gs(x, lab)                                         # noqa: E731
+else:
+    for _ in range(2): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps

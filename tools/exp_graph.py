@@ -50,8 +50,8 @@ with torch.cuda.stream(s):
         step()
 torch.cuda.current_stream().wait_stream(s)
 torch.cuda.synchronize(); print("warm ok", flush=True)
-eager_ms, l_e = timeit(step, steps)
-print("eager", eager_ms, flush=True)
+# capture straight after the side-stream warm-up (an eager step on the default stream in between leaves autograd state
+# that makes hipStreamEndCapture crash on ROCm 7.2), time the replays, then time eager last
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     static_loss = step()
@@ -59,5 +59,7 @@ print("captured", flush=True)
 graph_ms, _ = timeit(g.replay, steps)
 l0 = float(static_loss)
 g.replay(); torch.cuda.synchronize()
-print(json.dumps({"model": which, "eager_ms": round(eager_ms, 2), "graph_ms": round(graph_ms, 2), "loss_after_replays": [l0, float(static_loss)],
+l1 = float(static_loss)
+eager_ms, l_e = timeit(step, steps)
+print(json.dumps({"model": which, "eager_ms": round(eager_ms, 2), "graph_ms": round(graph_ms, 2), "loss_after_replays": [l0, l1],
                   "eager_loss": float(l_e)}))

@@ -8,10 +8,11 @@ import loss as L
 import Model
 L.CLASS_NUMBER = 2
 torch.manual_seed(0)
-m = Model.UNet(1, 2, 8, compute_dtype="fp16").cuda().train()
-x = torch.randn(2, 1, 64, 64, device="cuda")
-lab = torch.randint(0, 2, (2, 64, 64), device="cuda").float()
 stage = sys.argv[1]
+F_, B_, S_ = (int(v) for v in (sys.argv[2:5] + ["8", "2", "64"][len(sys.argv) - 2:]))
+m = Model.UNet(1, 2, F_, compute_dtype="fp16").cuda().train()
+x = torch.randn(B_, 1, S_, S_, device="cuda")
+lab = torch.randint(0, 2, (B_, S_, S_), device="cuda").float()
 s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
 opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
 def fwd():

@@ -272,9 +272,17 @@ class VisionTransformer(nn.Module):
         cfg = self.config
         self._step += 1
         step = self._step
+        seed_dev = None
+        if self.training and x.is_cuda:
+            # device-side step counter for the dropout streams: advanced by a device op, so it also advances when this
+            # forward is replayed from a captured HIP graph (where the host-side `step` is frozen at capture time)
+            if getattr(self, "_drop_step", None) is None or self._drop_step.device != x.device:
+                self._drop_step = torch.zeros(1, dtype=torch.int32, device=x.device)
+            self._drop_step.add_(1)
+            seed_dev = self._drop_step
 
         def run(record, in_needs):
-            tape = TUTape(dtype, training=self.training, record=record, seed=step,
+            tape = TUTape(dtype, training=self.training, record=record, seed=step, seed_dev=seed_dev,
                           loss_scale=G.default_loss_scale(dtype, N * H * W),
                           grad_sink=getattr(self, "_umi_grad_sink", None) if record else None)
             a = tape.input_nchw(x, needs_grad=False)

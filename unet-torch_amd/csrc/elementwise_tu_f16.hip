@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void ew8_kernel(const half_t* __restrict__ x, 
 
 __global__ __launch_bounds__(256) void dropout8_kernel(const half_t* __restrict__ x, int ldx, half_t* __restrict__ y, int ldy,
                                                        unsigned char* __restrict__ mask, int bwd, float p, unsigned seed,
-                                                       long M, int C8, const float4* __restrict__ tx) {
+                                                       long M, int C8, const float4* __restrict__ tx,
+                                                       const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B9u;          // same offset rule as the scalar kernel
     const long total = M * C8;
     const float scale = 1.f / (1.f - p);
     const int C = C8 * 8;
@@ -267,11 +269,11 @@ bool umi_ew_f16v(int mode, const void* x, int ldx, const void* g, int ldg, void*
 }
 
 bool umi_dropout_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
-                      const void* tx, hipStream_t s) {
+                      const void* tx, const unsigned* seed_dev, hipStream_t s) {
     if (C % 8 || ldx % 8 || ldy % 8 || !al16(x) || !al16(y) || (((uintptr_t)mask) & 7)) return false;
     const int C8 = C / 8;
     hipLaunchKernelGGL(dropout8_kernel, dim3(grid8(M * C8)), dim3(256), 0, s, (const half_t*)x, ldx, (half_t*)y, ldy,
-                       (unsigned char*)mask, backward, p, seed, M, C8, (const float4*)tx);
+                       (unsigned char*)mask, backward, p, seed, M, C8, (const float4*)tx, seed_dev);
     return true;
 }
 

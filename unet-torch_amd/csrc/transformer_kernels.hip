@@ -313,7 +313,9 @@ __device__ __forceinline__ unsigned hash32(unsigned a, unsigned b) {           /
 // fwd (g == nullptr): keep = u >= p ; y = keep ? x/(1-p) : 0 ; mask byte written.   bwd: y = g * mask/(1-p)
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, unsigned char* __restrict__ mask,
-                               int bwd, float p, unsigned seed, long M, int C, const float4* __restrict__ tx) {
+                               int bwd, float p, unsigned seed, long M, int C, const float4* __restrict__ tx,
+                               const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B9u;          // per-replay stream offset when the step runs from a HIP graph
     const long total = M * C;
     const float scale = 1.f / (1.f - p);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -554,7 +556,7 @@ bool umi_gn_bwd_reduce_f16v(const void* dy, int lddy, const void* y, int ldy, co
 bool umi_ew_f16v(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C, long bcast_rows,
                  hipStream_t s);
 bool umi_dropout_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
-                      const void* tx, hipStream_t s);
+                      const void* tx, const unsigned* seed_dev, hipStream_t s);
 int umi_ln_bwd_rows_f16v();
 bool umi_ln_bwd_f16v(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
                      void* dx, int lddx, float* part, long M, int C, hipStream_t s);
@@ -730,16 +732,16 @@ extern "C" int umi_elementwise(int mode, const void* x, int ldx, const void* g, 
 }
 
 extern "C" int umi_dropout(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M,
-                           int C, int dtype, const void* tx, umi_stream_t st) {
+                           int C, int dtype, const void* tx, const unsigned* seed_dev, umi_stream_t st) {
     if (!x || !y || !mask || p < 0.f || p >= 1.f) return UMI_ERR_BADARG;
-    if (dtype == UMI_F16 && umi_dropout_f16v(x, ldx, y, ldy, mask, backward, p, seed, M, C, tx, (hipStream_t)st)) {
+    if (dtype == UMI_F16 && umi_dropout_f16v(x, ldx, y, ldy, mask, backward, p, seed, M, C, tx, seed_dev, (hipStream_t)st)) {
         UMI_LAUNCH_CHECK();
         return UMI_OK;
     }
     const int grid = grid_for(M * C);
     DT_SWITCH(dtype,
-        hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const float*)x, ldx, (float*)y, ldy, (unsigned char*)mask, backward, p, seed, M, C, (const float4*)tx),
-        hipLaunchKernelGGL(dropout_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const half_t*)x, ldx, (half_t*)y, ldy, (unsigned char*)mask, backward, p, seed, M, C, (const float4*)tx))
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const float*)x, ldx, (float*)y, ldy, (unsigned char*)mask, backward, p, seed, M, C, (const float4*)tx, seed_dev),
+        hipLaunchKernelGGL(dropout_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)st, (const half_t*)x, ldx, (half_t*)y, ldy, (unsigned char*)mask, backward, p, seed, M, C, (const float4*)tx, seed_dev))
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }

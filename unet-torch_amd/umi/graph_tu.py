@@ -15,10 +15,11 @@ from .graph import Act, Tape, _wants_grad
 
 
 class TUTape(Tape):
-    def __init__(self, *a, seed=0, **k):
+    def __init__(self, *a, seed=0, seed_dev=None, **k):
         super().__init__(*a, **k)
         self._seed = int(seed)
-        self._drop_count = 0
+        self._seed_dev = seed_dev         # int32 device scalar mixed into every dropout seed inside the kernel: a step replayed
+        self._drop_count = 0              # from a captured HIP graph (host-side `seed` frozen) still draws fresh masks
 
     # gradients of a value with several consumers are summed by a libunetmi kernel (no torch arithmetic)
     def _give(self, act, g):
@@ -231,7 +232,7 @@ class TUTape(Tape):
         out = torch.empty_like(a.raw)
         mask = torch.empty(a.raw.numel(), dtype=torch.uint8, device=a.raw.device)
         self._drop_count += 1
-        ops_tu.dropout(a.raw, out, mask, False, p, self._seed * 7919 + self._drop_count)
+        ops_tu.dropout(a.raw, out, mask, False, p, self._seed * 7919 + self._drop_count, seed_dev=self._seed_dev)
         o = Act(out, None)
         if self.record:
             def bwd():

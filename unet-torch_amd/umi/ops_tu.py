@@ -111,10 +111,11 @@ def add_bcast(a, rows_tensor, y, bcast_rows):
     elementwise(3, a, rows_tensor, y, bcast_rows)
 
 
-def dropout(x, y, mask, backward, p, seed, tx=None):
+def dropout(x, y, mask, backward, p, seed, tx=None, seed_dev=None):
+    """seed_dev: optional int32 device scalar added into the seed inside the kernel (HIP-graph replays)."""
     M, C, ldx = _rows(x)
     L.check(L.fn("umi_dropout")(x.data_ptr(), ldx, y.data_ptr(), _rows(y)[2], mask.data_ptr(), int(backward), p,
-                                seed & 0xFFFFFFFF, M, C, _dt(x), _ptr(tx), _stream()), "umi_dropout")
+                                seed & 0xFFFFFFFF, M, C, _dt(x), _ptr(tx), _ptr(seed_dev), _stream()), "umi_dropout")
 
 
 def attn_fwd(q, k, v, o, heads):
