@@ -192,7 +192,10 @@ def main():
     L.CLASS_NUMBER = a.ncls
     torch.manual_seed(0)                         # identical initial weights on every rank
     model = Model.UNet(a.cin, a.ncls, a.features, compute_dtype=a.dtype).to(dev).train()
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    from umi import optim as umi_optim
+    # same arithmetic and state as torch.optim.SGD (reference config.yml:15-18), one launch per step; UMI_TORCH_OPTIM=1 -> torch's
+    opt_cls = torch.optim.SGD if os.environ.get("UMI_TORCH_OPTIM") == "1" else umi_optim.SGD
+    opt = opt_cls(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     reducer = ddp.GradReducer(model, world) if world > 1 else None
 
     g = torch.Generator(device=dev)

@@ -206,6 +206,40 @@ int umi_dice_ce_fwd(const float* logits, const void* target, int target_dtype, i
 int umi_dice_ce_bwd(const float* logits, const void* target, int target_dtype, const float* stats, const float* gout, int N,
                     int C, long HW, float* dlogits, umi_stream_t stream);
 
+/* Multi-tensor optimizer step: torch.optim.SGD / torch.optim.Adam arithmetic (reference train.py:341-347) on every parameter
+ * tensor of a model in ONE launch.  `descs` is a DEVICE array of n_desc umi_optim_desc sorted by blk0; a tensor of n elements
+ * occupies ceil(n / umi_optim_block_elems()) consecutive blocks starting at blk0; total_blocks = the sum.
+ *   SGD:  g += wd*p; m = first_step ? g : momentum*m + (1-dampening)*g; g = nesterov ? g + momentum*m : m; p -= lr*g
+ *         (s0 = momentum buffer, NULL when momentum == 0; s1 unused)
+ *   Adam: g += wd*p; m += (1-beta1)*(g-m); v = beta2*v + (1-beta2)*g*g; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)
+ *         (s0 = exp_avg, s1 = exp_avg_sq; step_size = lr / (1-beta1^t), bc2_sqrt = sqrt(1-beta2^t), computed by the host) */
+typedef struct umi_optim_desc {
+    float* p;            /* parameter (fp32 master), updated in place */
+    const float* g;      /* gradient */
+    float* s0;
+    float* s1;
+    long n;              /* elements */
+    int blk0;
+    int pad_;
+} umi_optim_desc;
+int umi_optim_block_elems(void);
+/* hyper-parameters are doubles (Python floats) and are rounded to fp32 where torch rounds them */
+int umi_optim_sgd_multi(const void* descs, int n_desc, int total_blocks, double lr, double momentum, double dampening,
+                        double weight_decay, int nesterov, int first_step, umi_stream_t stream);
+int umi_optim_adam_multi(const void* descs, int n_desc, int total_blocks, double step_size, double beta1, double beta2,
+                         double bc2_sqrt, double eps, double weight_decay, umi_stream_t stream);
+
+/* umi_pack_kn / umi_pack_kn8 of many weight tensors in one launch (all the convolution weights of a model after an
+ * optimizer step).  `descs`: DEVICE array sorted by blk0; an entry owns ceil(T*Kpad*Npad / umi_pack_block_elems()) blocks. */
+typedef struct umi_pack_desc {
+    const float* src;
+    void* dst;
+    long st, sk, sn;
+    int T, K, N, flip_t, Kpad, Npad, k8, blk0;
+} umi_pack_desc;
+int umi_pack_block_elems(void);
+int umi_pack_kn_multi(const void* descs, int n_desc, int total_blocks, int dtype, umi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,3 +296,112 @@ def test_colsum_paths(M, C, pad):
     xd = buf.to(DEV)[..., :C]
     ops.colsum(xd, out, 0.25)
     assert (out.cpu().double() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+# ---- multi-tensor optimizer step and weight re-pack ---------------------------------------------
+def _param_set(gen):
+    """Tensors of very unequal sizes, incl. odd lengths and 4-byte-aligned views (flat-bucket slices)."""
+    shapes = [(64, 32, 3, 3), (64,), (2,), (2, 64, 1, 1), (128, 64, 3, 3), (5, 7), (1,), (4099,), (300, 41)]
+    ps = [torch.randn(s, generator=gen).to(DEV) for s in shapes]
+    flat = torch.randn(3 + sum(p.numel() for p in ps), generator=gen).to(DEV)
+    return ps, flat
+
+
+def _run_optim(make, steps, flat_grads):
+    gen = torch.Generator().manual_seed(5)
+    ps, flat = _param_set(gen)
+    params = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = make(params)
+    for s in range(steps):
+        off = 3                                             # misaligned start: views are only 4-byte aligned
+        for p in params:
+            g = torch.randn(p.shape, generator=gen).to(DEV) * (0.5 + s)
+            if flat_grads:
+                v = flat[off:off + p.numel()].view(p.shape)
+                v.copy_(g)
+                p.grad = v
+                off += p.numel()
+            else:
+                p.grad = g
+        if s == 2:
+            for group in opt.param_groups:                  # poly-LR style rewrite (reference Trainer.py:722-725)
+                group["lr"] *= 0.7
+        opt.step()
+    torch.cuda.synchronize()
+    return [p.detach().cpu() for p in params], opt
+
+
+@pytest.mark.parametrize("kw", [dict(lr=0.01, momentum=0.9, weight_decay=1e-4),
+                                dict(lr=0.05),
+                                dict(lr=0.02, momentum=0.8, nesterov=True, weight_decay=1e-3),
+                                dict(lr=0.02, momentum=0.9, dampening=0.1)])
+@pytest.mark.parametrize("flat_grads", [False, True])
+def test_optim_sgd_matches_torch(kw, flat_grads):
+    _gpu()
+    from umi import optim as uo
+    mine, o1 = _run_optim(lambda ps: uo.SGD(ps, **kw), 5, flat_grads)
+    ref, o2 = _run_optim(lambda ps: torch.optim.SGD(ps, foreach=True, **kw), 5, flat_grads)
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)       # same op order; fma contraction may differ by an ulp
+    s1, s2 = o1.state_dict(), o2.state_dict()
+    assert s1["state"].keys() == s2["state"].keys()
+    for k in s1["state"]:
+        assert s1["state"][k].keys() == s2["state"][k].keys()
+        if "momentum_buffer" in s1["state"][k] and s1["state"][k]["momentum_buffer"] is not None:
+            torch.testing.assert_close(s1["state"][k]["momentum_buffer"].cpu(), s2["state"][k]["momentum_buffer"].cpu(),
+                                       rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("kw", [dict(lr=5e-4, weight_decay=1e-4), dict(lr=1e-3, betas=(0.8, 0.95), eps=1e-6)])
+def test_optim_adam_matches_torch(kw):
+    _gpu()
+    from umi import optim as uo
+    mine, o1 = _run_optim(lambda ps: uo.Adam(ps, **kw), 6, True)
+    ref, o2 = _run_optim(lambda ps: torch.optim.Adam(ps, foreach=True, **kw), 6, True)
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a, b, rtol=5e-6, atol=2e-7)
+    s1, s2 = o1.state_dict()["state"], o2.state_dict()["state"]
+    for k in s1:
+        assert s1[k].keys() == s2[k].keys() and float(s1[k]["step"]) == float(s2[k]["step"]) == 6.0
+        for name in ("exp_avg", "exp_avg_sq"):
+            # one-ulp differences of O(1) intermediates (fma contraction) show as absolute error where exp_avg cancels
+            torch.testing.assert_close(s1[k][name].cpu(), s2[k][name].cpu(), rtol=5e-6, atol=1e-6)
+
+
+def test_optim_refuses_cpu_parameters():
+    _gpu()
+    from umi import optim as uo
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        uo.SGD([p], lr=0.1).step()
+
+
+def test_pack_cache_multi_repack_is_bit_identical_to_single_packs():
+    _, ops = _gpu()
+    gen = torch.Generator().manual_seed(9)
+    ws = {"conv_fwd": torch.randn(64, 32, 3, 3, generator=gen), "conv_dgrad": torch.randn(128, 64, 3, 3, generator=gen),
+          "convT_fwd": torch.randn(64, 32, 2, 2, generator=gen), "convT_dgrad": torch.randn(32, 16, 2, 2, generator=gen)}
+    params = {k: torch.nn.Parameter(v.to(DEV)) for k, v in ws.items()}
+    params["small"] = torch.nn.Parameter(torch.randn(2, 64, 1, 1, generator=gen).to(DEV))
+    cache = ops.PackCache()
+    combos = [(k, params[k], torch.float16, True) for k in ws] + [(k, params[k], torch.float16, False) for k in ws] + \
+             [("conv_fwd", params["small"], torch.float16, False), ("conv_fwd", params["conv_fwd"], torch.float32, False)]
+
+    def check():
+        for kind, w, dt, k8 in combos:
+            got = cache.get(kind, w, dt, k8)
+            want = ops.PACKERS[kind](w.detach(), dt, k8=k8)
+            assert torch.equal(got.cpu(), want.cpu()), (kind, dt, k8)
+    check()                                                  # first use: packed one by one
+    ptrs = [cache.get(*c).data_ptr() for c in combos]
+    with torch.no_grad():
+        for w in params.values():
+            w.mul_(1.5).add_(0.25)                           # in-place update bumps ._version -> every entry stale
+    cache.refresh()                                          # one launch per storage dtype
+    assert all(e.ver == cache._ver(e.w()) for e in cache.ents.values())
+    check()
+    assert ptrs == [cache.get(*c).data_ptr() for c in combos]   # persistent buffers (no per-step allocation)
+    with torch.no_grad():
+        params["conv_dgrad"].zero_()
+    check()                                                  # a stale entry met without refresh() is re-packed on use

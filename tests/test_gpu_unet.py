@@ -387,3 +387,37 @@ def test_dropout_kernel_with_consumer_transform_and_unet_dropout_mode():
     with torch.no_grad():
         e1, e2 = m(xin), m(xin)
     assert torch.equal(e1, e2)
+
+
+def test_fused_optimizer_and_pack_cache_leave_the_training_trajectory_unchanged(monkeypatch):
+    """umi.optim.SGD + the model's PackCache (one update launch + one re-pack launch per step) against
+    torch.optim.SGD + per-use packing, same seeds: same losses and weights up to fp32 rounding of the update."""
+    import Model
+    import loss as L
+    from umi import optim as uo
+    L.CLASS_NUMBER = 2
+
+    def run(fused):
+        monkeypatch.setenv("UMI_NO_PACK_CACHE", "0" if fused else "1")
+        torch.manual_seed(3)
+        m = Model.UNet(1, 2, 16, compute_dtype=torch.float16).to("cuda").train()
+        opt = (uo.SGD if fused else torch.optim.SGD)(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(11)
+        losses = []
+        for _ in range(4):
+            x = torch.randn(2, 1, 64, 64, generator=g).cuda()
+            y = torch.randint(0, 2, (2, 64, 64), generator=g).float().cuda()
+            opt.zero_grad(set_to_none=True)
+            l = L.calc_loss(m(x), y, loss_type="dice_bce_mc")
+            l.backward()
+            opt.step()
+            losses.append(float(l.detach()))
+        if fused:
+            assert len(m._umi_pack_cache.ents) >= 40      # every conv weight in both layouts
+        return losses, [p.detach().float().cpu() for p in m.parameters()]
+
+    l1, p1 = run(True)
+    l0, p0 = run(False)
+    assert max(abs(a - b) for a, b in zip(l1, l0)) < 2e-5, (l1, l0)
+    for a, b in zip(p1, p0):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-6)

@@ -18,7 +18,9 @@ cfg.patches.grid = (size // 16, size // 16)
 L.CLASS_NUMBER = 2
 torch.manual_seed(0)
 m = VisionTransformer(cfg, img_size=size, num_classes=2, compute_dtype=dtype).cuda().train()
-opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+from umi import optim as umi_optim
+opt = (torch.optim.SGD if os.environ.get("UMI_TORCH_OPTIM") == "1" else umi_optim.SGD)(
+    m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
 x = torch.randn(B, 1, size, size, device="cuda")
 lab = torch.randint(0, 2, (B, size, size), device="cuda").float()
 def step():

@@ -71,7 +71,8 @@ def _run_tape(module, inputs, build):
     def run(record, in_needs):
         tape = G.Tape(dtype, training=module.training, record=record,
                       loss_scale=G.default_loss_scale(dtype, N * H * W),
-                      grad_sink=getattr(module, "_umi_grad_sink", None) if record else None)
+                      grad_sink=getattr(module, "_umi_grad_sink", None) if record else None,
+                      pack_cache=G.pack_cache_of(module))
         acts = [tape.input_nchw(x, needs_grad=need) for x, need in zip(inputs, in_needs)]
         out_act = build(tape, *acts)
         if out_act.tx is None and out_act.raw.dtype == torch.float32:

@@ -284,7 +284,8 @@ class VisionTransformer(nn.Module):
         def run(record, in_needs):
             tape = TUTape(dtype, training=self.training, record=record, seed=step, seed_dev=seed_dev,
                           loss_scale=G.default_loss_scale(dtype, N * H * W),
-                          grad_sink=getattr(self, "_umi_grad_sink", None) if record else None)
+                          grad_sink=getattr(self, "_umi_grad_sink", None) if record else None,
+                          pack_cache=G.pack_cache_of(self))
             a = tape.input_nchw(x, needs_grad=False)
             emb = self.transformer.embeddings
             feat, skips = build_resnet(tape, a, emb.hybrid_model)

@@ -1,0 +1,194 @@
+// Multi-tensor parameter update and weight re-pack: one launch per training step each instead of one per tensor.
+//
+//   umi_optim_sgd_multi / umi_optim_adam_multi   torch.optim.SGD / Adam arithmetic (reference train.py:341-347: SGD lr 0.01
+//       momentum 0.9 wd 1e-4, Adam lr 5e-4 wd 1e-4), fp32, same operation order and roundings as torch's foreach kernels.
+//   umi_pack_kn_multi                            umi_pack_kn / umi_pack_kn8 of every convolution weight of a model.
+//
+// All three walk a descriptor table that lives in device memory.  A workgroup owns one fixed-size block of ONE tensor
+// (`blk0` = first block of a descriptor, found by binary search), so the grid is balanced however unequal the tensors
+// are (a U-Net has 3x3x1024x1024 weights next to 64-element BatchNorm vectors).  HBM-bound streaming work: 16-byte
+// accesses whenever the four pointers of a tensor allow it.
+#include "common.h"
+
+namespace {
+
+struct OptDesc {           // mirrors umi_optim_desc (include/unetmi.h)
+    float* p;
+    const float* g;
+    float* s0;
+    float* s1;
+    long n;
+    int blk0;
+    int pad_;
+};
+
+struct PackDesc {          // mirrors umi_pack_desc
+    const float* src;
+    void* dst;
+    long st, sk, sn;
+    int T, K, N, flip_t, Kpad, Npad, k8, blk0;
+};
+
+constexpr int OPT_BLOCK = 4096;      // elements per workgroup (256 threads x 4 x float4)
+constexpr int PACK_BLOCK = 2048;     // packed elements per workgroup
+
+template <typename D>
+__device__ inline int find_desc(const D* d, int n, int blk) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (d[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+struct SgdArgs { float lr, momentum, omd, wd; int nesterov, first; };   // omd = 1 - dampening
+
+__device__ inline void sgd_one(float& p, float g, float& m, const SgdArgs a) {
+    if (a.wd != 0.f) g = fmaf(a.wd, p, g);                            // grad.add(param, alpha=wd)
+    if (a.momentum != 0.f) {
+        if (a.first) m = g;                                            // buf = clone(grad)
+        else {
+            float mm = __fmul_rn(m, a.momentum);                       // buf.mul_(momentum)
+            m = a.omd == 1.f ? __fadd_rn(mm, g) : fmaf(a.omd, g, mm);   // .add_(grad, alpha=1-dampening)
+        }
+        g = a.nesterov ? fmaf(a.momentum, m, g) : m;
+    }
+    p = fmaf(-a.lr, g, p);                                             // param.add_(grad, alpha=-lr)
+}
+
+struct AdamArgs { float step_size, omb1, beta2, omb2, bc2_sqrt, eps, wd; };   // omb = 1 - beta, rounded from double
+
+__device__ inline void adam_one(float& p, float g, float& m, float& v, const AdamArgs a) {
+    if (a.wd != 0.f) g = fmaf(a.wd, p, g);                            // grad.add(param, alpha=wd)  (L2, not AdamW)
+    m = fmaf(a.omb1, g - m, m);                                        // exp_avg.lerp_(grad, 1-beta1)
+    v = fmaf(a.omb2 * g, g, __fmul_rn(v, a.beta2));                   // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = __fdiv_rn(__fsqrt_rn(v), a.bc2_sqrt) + a.eps;
+    p = fmaf(-a.step_size, __fdiv_rn(m, denom), p);                    // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+template <bool ADAM, typename A>
+__global__ __launch_bounds__(256) void optim_multi_kernel(const OptDesc* __restrict__ descs, int n_desc, A a) {
+    const int blk = blockIdx.x;
+    const OptDesc d = descs[find_desc(descs, n_desc, blk)];
+    const long base = (long)(blk - d.blk0) * OPT_BLOCK;
+    const long left = d.n - base;
+    const int cnt = left < OPT_BLOCK ? (int)left : OPT_BLOCK;
+    float* p = d.p + base;
+    const float* g = d.g + base;
+    float* s0 = d.s0 ? d.s0 + base : nullptr;
+    float* s1 = d.s1 ? d.s1 + base : nullptr;
+    const unsigned long al = (unsigned long)p | (unsigned long)g | (unsigned long)s0 | (unsigned long)s1;
+    if ((al & 15) == 0) {
+        for (int i = threadIdx.x * 4; i + 4 <= cnt; i += 1024) {
+            float4 pv = *reinterpret_cast<float4*>(p + i);
+            const float4 gv = *reinterpret_cast<const float4*>(g + i);
+            float4 mv = s0 ? *reinterpret_cast<float4*>(s0 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 vv = (ADAM && s1) ? *reinterpret_cast<float4*>(s1 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (ADAM) {
+                adam_one(pv.x, gv.x, mv.x, vv.x, a); adam_one(pv.y, gv.y, mv.y, vv.y, a);
+                adam_one(pv.z, gv.z, mv.z, vv.z, a); adam_one(pv.w, gv.w, mv.w, vv.w, a);
+                *reinterpret_cast<float4*>(s1 + i) = vv;
+            } else {
+                sgd_one(pv.x, gv.x, mv.x, a); sgd_one(pv.y, gv.y, mv.y, a);
+                sgd_one(pv.z, gv.z, mv.z, a); sgd_one(pv.w, gv.w, mv.w, a);
+            }
+            *reinterpret_cast<float4*>(p + i) = pv;
+            if (s0) *reinterpret_cast<float4*>(s0 + i) = mv;
+        }
+        const int tail0 = cnt & ~3;
+        const int i = tail0 + threadIdx.x;
+        if (i < cnt) {
+            float pv = p[i], mv = s0 ? s0[i] : 0.f;
+            if constexpr (ADAM) { float vv = s1[i]; adam_one(pv, g[i], mv, vv, a); s1[i] = vv; }
+            else sgd_one(pv, g[i], mv, a);
+            p[i] = pv;
+            if (s0) s0[i] = mv;
+        }
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            float pv = p[i], mv = s0 ? s0[i] : 0.f;
+            if constexpr (ADAM) { float vv = s1[i]; adam_one(pv, g[i], mv, vv, a); s1[i] = vv; }
+            else sgd_one(pv, g[i], mv, a);
+            p[i] = pv;
+            if (s0) s0[i] = mv;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restrict__ descs, int n_desc) {
+    const int blk = blockIdx.x;
+    const PackDesc d = descs[find_desc(descs, n_desc, blk)];
+    const long total = (long)d.T * d.Kpad * d.Npad;
+    const long base = (long)(blk - d.blk0) * PACK_BLOCK;
+    T* dst = (T*)d.dst;
+    const int kb8 = d.Kpad >> 3;
+#pragma unroll 2
+    for (int j = 0; j < PACK_BLOCK / 256; ++j) {
+        const long i = base + j * 256 + threadIdx.x;
+        if (i >= total) break;
+        int n, k, t;
+        if (d.k8) {                      // dst[t][k/8][n][k%8]
+            const int k8 = (int)(i & 7);
+            long r = i >> 3;
+            n = (int)(r % d.Npad); r /= d.Npad;
+            const int kb = (int)(r % kb8);
+            t = (int)(r / kb8);
+            k = kb * 8 + k8;
+        } else {                         // dst[t][k][n]
+            n = (int)(i % d.Npad);
+            const long r = i / d.Npad;
+            k = (int)(r % d.Kpad);
+            t = (int)(r / d.Kpad);
+        }
+        float v = 0.f;
+        if (k < d.K && n < d.N) {
+            const int ts = d.flip_t ? (d.T - 1 - t) : t;
+            v = d.src[ts * d.st + k * d.sk + n * d.sn];
+        }
+        dst[i] = (T)v;
+    }
+}
+
+}  // namespace
+
+extern "C" int umi_optim_block_elems(void) { return OPT_BLOCK; }
+extern "C" int umi_pack_block_elems(void) { return PACK_BLOCK; }
+
+// Hyper-parameters arrive as doubles and are rounded to fp32 exactly where torch rounds them (1 - dampening and 1 - beta
+// are formed in double first: 1 - 0.999 is 0.001f there, not 1.f - 0.999f).
+extern "C" int umi_optim_sgd_multi(const void* descs, int n_desc, int total_blocks, double lr, double momentum,
+                                   double dampening, double weight_decay, int nesterov, int first_step,
+                                   umi_stream_t stream) {
+    if (!descs || n_desc <= 0 || total_blocks <= 0) return UMI_ERR_BADARG;
+    SgdArgs a{(float)lr, (float)momentum, (float)(1.0 - dampening), (float)weight_decay, nesterov, first_step};
+    hipLaunchKernelGGL((optim_multi_kernel<false, SgdArgs>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const OptDesc*)descs, n_desc, a);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_optim_adam_multi(const void* descs, int n_desc, int total_blocks, double step_size, double beta1,
+                                    double beta2, double bc2_sqrt, double eps, double weight_decay, umi_stream_t stream) {
+    if (!descs || n_desc <= 0 || total_blocks <= 0) return UMI_ERR_BADARG;
+    AdamArgs a{(float)step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps,
+               (float)weight_decay};
+    hipLaunchKernelGGL((optim_multi_kernel<true, AdamArgs>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const OptDesc*)descs, n_desc, a);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_pack_kn_multi(const void* descs, int n_desc, int total_blocks, int dtype, umi_stream_t stream) {
+    if (!descs || n_desc <= 0 || total_blocks <= 0) return UMI_ERR_BADARG;
+    if (dtype == UMI_F16)
+        hipLaunchKernelGGL((pack_multi_kernel<half_t>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const PackDesc*)descs, n_desc);
+    else if (dtype == UMI_F32)
+        hipLaunchKernelGGL((pack_multi_kernel<float>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const PackDesc*)descs, n_desc);
+    else return UMI_ERR_BADARG;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}

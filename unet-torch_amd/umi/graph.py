@@ -45,8 +45,9 @@ class Act:
 
 
 class Tape:
-    def __init__(self, dtype, training, record, loss_scale=1.0, grad_sink=None):
+    def __init__(self, dtype, training, record, loss_scale=1.0, grad_sink=None, pack_cache=None):
         self.dtype = dtype
+        self.pack_cache = pack_cache      # ops.PackCache of the model that owns the parameters, or None (pack per use)
         self.grad_sink = grad_sink        # umi.ddp.GradReducer (flat buckets + overlapped all-reduce) or None
         self.training = training          # BatchNorm uses batch statistics
         self.record = record              # keep closures for backward
@@ -63,6 +64,13 @@ class Tape:
     def alloc(self, N, H, W, C, dtype=None, zero=False, device=None):
         f = torch.zeros if zero else torch.empty
         return f((N, H, W, C), dtype=dtype or self.dtype, device=device)
+
+    def _pack(self, kind, weight, wf, k8):
+        """Kernel-layout copy of a convolution weight: from the model's PackCache when `weight` is a parameter."""
+        c = self.pack_cache
+        if c is not None and isinstance(weight, torch.nn.Parameter) and weight.dtype == torch.float32:
+            return c.get(kind, weight, self.dtype, k8)
+        return ops.PACKERS[kind](wf, self.dtype, k8=k8)
 
     def _new_pgrad(self, p):
         """fp32 tensor the wgrad kernel writes into: a slot of the reducer's flat bucket when present."""
@@ -125,7 +133,7 @@ class Tape:
         if out is None:
             out = self.alloc(N, Ho, Wo, Co, device=a.raw.device)
         wf = weight.detach().float()
-        part = ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(wf, self.dtype, k8=bool(lay)), None, out,
+        part = ops.conv_fwd(a.raw, a.tx, lambda lay: self._pack("conv_fwd", weight, wf, bool(lay)), None, out,
                             R, S, stride, pad, want_stats=self.training)
         if self.training:
             mom = bn.momentum if bn.momentum is not None else 0.1
@@ -166,12 +174,12 @@ class Tape:
                     part = None
                     if (input_exclusive and _fuse_bnred() and a.grad is None and a.parts is None and a.bn_rstd is not None
                             and a.tx is not None and (R, S, pad) == (3, 3, 1) and self.dtype == torch.float16):
-                        part = ops.conv_dgrad_bnred(o.grad, ops.pack_conv_dgrad(wf, self.dtype, k8=True), dx, a.raw, a.tx,
+                        part = ops.conv_dgrad_bnred(o.grad, self._pack("conv_dgrad", weight, wf, True), dx, a.raw, a.tx,
                                                     a.bn_rstd)
                     if part is not None:
                         a.bn_part = part
                     else:
-                        ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(wf, self.dtype, k8=bool(lay)), None, dx,
+                        ops.conv_fwd(o.grad, None, lambda lay: self._pack("conv_dgrad", weight, wf, bool(lay)), None, dx,
                                      R, S, 1, R - 1 - pad)
                     self._give(a, dx)
             self.steps.append(bwd)
@@ -185,7 +193,7 @@ class Tape:
         out = self.alloc(N, H + 2 * pad - R + 1, W + 2 * pad - S + 1, Co, dtype=out_dtype or self.dtype,
                          device=a.raw.device)
         wf0 = weight.detach().float()
-        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(wf0, self.dtype, k8=bool(lay)),
+        ops.conv_fwd(a.raw, a.tx, lambda lay: self._pack("conv_fwd", weight, wf0, bool(lay)),
                      bias.detach().float() if bias is not None else None, out, R, S, 1, pad)
         o = Act(out, None)
         if self.record:
@@ -204,7 +212,7 @@ class Tape:
                 if _wants_grad(a):
                     dx = self.alloc(N, H, W, Ci, device=out.device)
                     wf = weight.detach().float()
-                    ops.conv_fwd(g, None, lambda lay: ops.pack_conv_dgrad(wf, self.dtype, k8=bool(lay)), None, dx,
+                    ops.conv_fwd(g, None, lambda lay: self._pack("conv_dgrad", weight, wf, bool(lay)), None, dx,
                                  R, S, 1, R - 1 - pad)
                     self._give(a, dx)
             self.steps.append(bwd)
@@ -245,7 +253,7 @@ class Tape:
         if dY or dX:
             dest.zero_()
         wf = weight.detach().float()
-        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_convT_fwd(wf, self.dtype, k8=bool(lay)),
+        ops.conv_fwd(a.raw, a.tx, lambda lay: self._pack("convT_fwd", weight, wf, bool(lay)),
                      bias.detach().float() if bias is not None else None, dest, 2, 2, 2, 0,
                      flags=L.CONV_UPSAMPLE2, up_offset=(oy, ox))
         o = Act(dest, None)
@@ -267,7 +275,7 @@ class Tape:
                 self._set_pgrad(weight, gw)
                 if _wants_grad(a):
                     dx = self.alloc(N, h, w, Cin, device=dest.device)
-                    ops.conv_fwd(g, None, lambda lay: ops.pack_convT_dgrad(wf, self.dtype, k8=bool(lay)), None, dx,
+                    ops.conv_fwd(g, None, lambda lay: self._pack("convT_dgrad", weight, wf, bool(lay)), None, dx,
                                  2, 2, 2, 0)
                     self._give(a, dx)
             self.steps.append(bwd)
@@ -339,6 +347,19 @@ class Tape:
         if self.loss_scale != 1.0:
             g = g / self.loss_scale
         return g.contiguous()
+
+
+def pack_cache_of(module):
+    """The module's cache of kernel-layout weight copies (ops.PackCache); stale entries (optimizer step, load_state_dict)
+    are re-packed here, in one launch, before the tape runs.  UMI_NO_PACK_CACHE=1 packs per use (A/B switch)."""
+    import os
+    if os.environ.get("UMI_NO_PACK_CACHE") == "1":
+        return None
+    c = module.__dict__.get("_umi_pack_cache")
+    if c is None:
+        c = module.__dict__["_umi_pack_cache"] = ops.PackCache()
+    c.refresh()
+    return c
 
 
 def _wants_grad(a: Act):

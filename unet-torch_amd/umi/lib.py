@@ -94,6 +94,12 @@ SIGNATURES = {
     "umi_dice_ce_ws_bytes": (c_size_t, [c_int, c_int, c_long]),
     "umi_dice_ce_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umi_dice_ce_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
+    "umi_optim_block_elems": (c_int, []),
+    "umi_optim_sgd_multi": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_int, c_void_p]),
+    "umi_optim_adam_multi": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_double,
+                                     c_void_p]),
+    "umi_pack_block_elems": (c_int, []),
+    "umi_pack_kn_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -1,0 +1,139 @@
+"""Fused multi-tensor optimizers behind the torch.optim façade.
+
+`SGD` / `Adam` subclass `torch.optim.SGD` / `torch.optim.Adam`: same constructor, `param_groups`, `state` and
+`state_dict()` layout (`momentum_buffer`; `step` / `exp_avg` / `exp_avg_sq`), so the reference's call sites
+(train.py:341-347 builds the optimizer, Trainer.py:719-725 drives it and rewrites `param_group['lr']` for the poly
+schedule) work unchanged.  `step()` updates every parameter of a group with ONE libunetmi launch
+(umi_optim_sgd_multi / umi_optim_adam_multi) that follows torch's operation order, instead of torch's 4-10 foreach
+launches per group.
+
+Parameters must live on the MI355X; there is no CPU path here (the CPU oracle uses torch.optim itself).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+
+
+def _bump(p):
+    # the kernels write through raw pointers: tell autograd (and ops.PackCache) that the parameter changed
+    torch.autograd.graph.increment_version(p)
+
+
+class _Table:
+    """Device descriptor table of one param group, rebuilt only when a pointer changes."""
+
+    def __init__(self):
+        self.key, self.dev, self.host, self.blocks, self.n = None, None, None, 0, 0
+
+    def get(self, rows):
+        key = tuple(rows)
+        if key != self.key:
+            blk = L.fn("umi_optim_block_elems")()
+            arr = np.zeros(len(rows), dtype=ops.OPTIM_DESC)
+            b0 = 0
+            for i, (p, g, s0, s1, n) in enumerate(rows):
+                arr[i] = (p, g, s0, s1, n, b0, 0)
+                b0 += (n + blk - 1) // blk
+            self.dev, self.host = ops.upload_table(arr)
+            self.key, self.blocks, self.n = key, b0, len(rows)
+        return self.dev.data_ptr(), self.n, self.blocks
+
+
+def _check(p):
+    if not p.is_cuda:
+        raise RuntimeError("umi.optim: parameters must be on the MI355X (device 'cuda'); use torch.optim on the CPU")
+    if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+        raise RuntimeError("umi.optim: dense fp32 parameters and gradients only")
+    if not p.is_contiguous():
+        raise RuntimeError("umi.optim: parameters must be contiguous")
+
+
+class SGD(torch.optim.SGD):
+    """torch.optim.SGD(lr, momentum, dampening, weight_decay, nesterov) with a single-launch step."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            if group.get("maximize") or group.get("differentiable"):
+                raise NotImplementedError("umi.optim.SGD: maximize / differentiable are not supported")
+            mom = float(group["momentum"])
+            rows = {True: [], False: []}             # first step of a momentum buffer? -> rows
+            touched = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _check(p)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                first, buf = False, None
+                if mom != 0.0:
+                    st = self.state[p]
+                    buf = st.get("momentum_buffer")
+                    if buf is None:
+                        buf = st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                        first = True
+                rows[first].append((p.data_ptr(), g.data_ptr(), 0 if buf is None else buf.data_ptr(), 0, p.numel()))
+                touched.append((p, g))
+            tabs = self.__dict__.setdefault("_umi_tables", {})
+            for first, rr in rows.items():
+                if not rr:
+                    continue
+                ptr, n, blocks = tabs.setdefault((gi, first), _Table()).get(rr)
+                L.check(L.fn("umi_optim_sgd_multi")(ptr, n, blocks, float(group["lr"]), mom, float(group["dampening"]),
+                                                    float(group["weight_decay"]), int(bool(group["nesterov"])), int(first),
+                                                    ops._stream()), "umi_optim_sgd_multi")
+            for p, _ in touched:
+                _bump(p)
+        return loss
+
+
+class Adam(torch.optim.Adam):
+    """torch.optim.Adam(lr, betas, eps, weight_decay) (L2 weight decay, no amsgrad) with a single-launch step."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            if group.get("amsgrad") or group.get("maximize") or group.get("differentiable") or group.get("capturable"):
+                raise NotImplementedError("umi.optim.Adam: amsgrad / maximize / differentiable / capturable are not supported")
+            if isinstance(group["lr"], torch.Tensor):
+                raise NotImplementedError("umi.optim.Adam: tensor learning rates are not supported")
+            b1, b2 = (float(b) for b in group["betas"])
+            by_step = {}
+            touched = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _check(p)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)            # host scalar, as torch keeps it
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                t = int(st["step"].item()) if not st["step"].is_cuda else int(st["step"])
+                by_step.setdefault(t, []).append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                  st["exp_avg_sq"].data_ptr(), p.numel()))
+                touched.append((p, g))
+            tabs = self.__dict__.setdefault("_umi_tables", {})
+            for slot, (t, rr) in enumerate(sorted(by_step.items())):
+                bc1 = 1.0 - b1 ** t
+                bc2 = 1.0 - b2 ** t
+                ptr, n, blocks = tabs.setdefault((gi, slot), _Table()).get(rr)
+                L.check(L.fn("umi_optim_adam_multi")(ptr, n, blocks, float(group["lr"]) / bc1, b1, b2, math.sqrt(bc2),
+                                                     float(group["eps"]), float(group["weight_decay"]), ops._stream()),
+                        "umi_optim_adam_multi")
+            for p, _ in touched:
+                _bump(p)
+        return loss
