@@ -240,6 +240,17 @@ typedef struct umi_pack_desc {
 int umi_pack_block_elems(void);
 int umi_pack_kn_multi(const void* descs, int n_desc, int total_blocks, int dtype, umi_stream_t stream);
 
+/* Inference pre-/post-processing, the steps either side of the network in the reference's test scripts.
+ * umi_znorm_hwc (test_mc3serousv5.py:115-127 `preprocess`): one HWC image, src_dtype 0 = uint8 (cv2.imread) or
+ *   1 = float32, C <= 4 -> out_chw[c'][p] = (img[p][c] - mean_c) / std_c as fp32, c' = reverse_channels ? C-1-c : c
+ *   (BGR -> RGB); mean and population std per channel in fp64 (numpy semantics), two-pass variance.
+ * umi_argmax_mask (test_mc3serousv5.py:883-885 softmax -> argmax -> uint8): mask[n][p] = argmax_c logits[n][c][p], first
+ *   maximum wins; softmax is monotone and therefore skipped. */
+size_t umi_znorm_ws_bytes(void);
+int umi_znorm_hwc(const void* img, int src_dtype, float* out_chw, long HW, int C, int reverse_channels, void* ws,
+                  size_t ws_bytes, umi_stream_t stream);
+int umi_argmax_mask(const float* logits, unsigned char* mask, int N, int C, long HW, umi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

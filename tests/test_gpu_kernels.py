@@ -405,3 +405,51 @@ def test_pack_cache_multi_repack_is_bit_identical_to_single_packs():
     with torch.no_grad():
         params["conv_dgrad"].zero_()
     check()                                                  # a stale entry met without refresh() is re-packed on use
+
+
+# ---- inference pre-/post-processing --------------------------------------------------------------
+def _ref_preprocess(img):
+    """Restatement of the reference's `preprocess` arithmetic (test_mc3serousv5.py:115-127), no resize."""
+    import numpy as np
+    mean3d = np.mean(img, axis=(0, 1))
+    std3d = np.std(img, axis=(0, 1))
+    x = (img - mean3d) / std3d
+    if img.ndim == 2:
+        return x.astype(np.float32)[None, None]
+    return np.ascontiguousarray(x.transpose((2, 0, 1))[::-1]).astype(np.float32)[None]
+
+
+@pytest.mark.parametrize("shape,dtype", [((37, 53), "uint8"), ((64, 48, 3), "uint8"), ((33, 31, 3), "float32"),
+                                         ((512, 512), "uint8")])
+def test_znorm_preprocess_matches_numpy(shape, dtype):
+    _gpu()
+    import numpy as np
+    from umi import infer
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=shape).astype(np.uint8) if dtype == "uint8" else \
+        (rng.standard_normal(shape) * 40 + 100).astype(np.float32)
+    # uint8 (what cv2.imread hands the reference) goes through fp64 in numpy; float32 images are this build's extension
+    # and use the same fp64 statistics (numpy would reduce them in fp32)
+    want = _ref_preprocess(img if dtype == "uint8" else img.astype(np.float64))
+    got = infer.preprocess(img).cpu().numpy()
+    assert got.shape == want.shape and got.dtype == np.float32
+    # fp64 statistics on both sides, one rounding to fp32: at most the last bit differs, and only rarely
+    np.testing.assert_allclose(got, want, rtol=0, atol=2.5e-7 * max(1.0, float(np.abs(want).max())))
+    assert (got == want).mean() > 0.995
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 2, 64, 64), (1, 4, 33, 47), (3, 3, 20, 20), (1, 7, 5, 9), (2, 2, 512, 512)])
+def test_argmax_mask_matches_softmax_argmax(N, C, H, W):
+    _gpu()
+    from umi import infer
+    gen = torch.Generator().manual_seed(N * 100 + C)
+    logits = torch.randn(N, C, H, W, generator=gen) * 3
+    logits[0, :, 0, 0] = 1.5                                  # an exact tie: the first class wins
+    want = torch.argmax(F.softmax(logits, dim=1), dim=1).to(torch.uint8)
+    got = infer.argmax_mask(logits.to(DEV)).cpu()
+    top2 = torch.topk(logits, 2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-5                  # softmax can merge near-ties that the logits still separate
+    assert got.dtype == torch.uint8 and got.shape == (N, H, W)
+    assert torch.equal(got[safe], want[safe])
+    assert int(got[0, 0, 0]) == 0
+    assert torch.equal(got, torch.argmax(logits, dim=1).to(torch.uint8))

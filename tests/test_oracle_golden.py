@@ -83,3 +83,38 @@ def test_state_dict_keys_and_shapes():
     m2 = ref_unet.RefUNet(-1, 2, 8, dropout=True)
     assert "down1.maxpool_conv.2.double_conv.0.weight" in m2.state_dict()
     assert m2.n_channels == 1
+
+
+def test_unet_multitask_matches_reference(golden_dir):
+    """oracle restatement of UNet_multitask (reference Model.py:172-262) against the reference's own
+    outputs, trained as Trainer.multi_task_train does (loss1 + loss2, Trainer.py:885-890)."""
+    g = np.load(os.path.join(golden_dir, "unet_multitask_1_2_8.npz"))
+    cin, ncls, feat = int(g["cin"]), int(g["ncls"]), int(g["feat"])
+    B, H, W, seed = int(g["B"]), int(g["H"]), int(g["W"]), int(g["seed"])
+    m = ref_unet.RefUNetMultitask(cin, ncls, feat, False)
+    assert len(m.state_dict()) == 176
+    assert all("init_sig." + k in g for k in m.state_dict())          # same state_dict keys as the reference
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed))
+    x, lab1 = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
+    _, lab2 = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed + 100)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    m.train()
+    for step in range(3):
+        o1, o2 = m(x)
+        loss = ref_unet.dice_bce_mc(o1, lab1, ncls) + ref_unet.dice_bce_mc(o2, lab2, ncls)
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            _close(o1.detach().numpy(), g["logits1"])
+            _close(o2.detach().numpy(), g["logits2"])
+            for k, p in m.named_parameters():
+                _sig_close(sig(p.grad), g["grad_sig." + k], rtol=5e-4)
+        assert abs(loss.item() - float(g[f"loss{step}"])) < 4e-6
+        opt.step()
+    for k, v in m.state_dict().items():
+        _sig_close(sig(v.float()), g["after3." + k], rtol=5e-4)
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x)
+    _close(e1.numpy(), g["eval_logits1"], rtol=1e-4, atol=1e-5)
+    _close(e2.numpy(), g["eval_logits2"], rtol=1e-4, atol=1e-5)

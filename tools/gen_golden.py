@@ -8,7 +8,7 @@ module level but never touch on the hot path: `torchvision`
 oracle/recipe.py (build-owned seeds), so only numeric *outputs* of the reference are
 serialised.  /root/reference never travels to the GPU box; these fixtures do.
 
-Usage:  python tools/gen_golden.py [--only unet|blocks|trainer|transunet] [--big]
+Usage:  python tools/gen_golden.py [--only unet|blocks|multitask|trainer|transunet] [--big]
 """
 import argparse
 import os
@@ -180,6 +180,47 @@ def gen_unet_case(Model, loss_mod, name, cin, ncls, feat, B, H, W, seed, full_lo
     print(f"wrote {name}.npz loss0={out['loss0']:.6f} margin_min={out['margin_min']:.3e}")
 
 
+def gen_unet_multitask(Model, loss_mod, name="unet_multitask_1_2_8", cin=1, ncls=2, feat=8, B=2, H=64, W=64, seed=9,
+                       steps=3):
+    """Reference UNet_multitask (Model.py:172-262) trained as Trainer.multi_task_train does (Trainer.py:885-890:
+    loss = calc_loss(out1, label1) + calc_loss(out2, label2)), SGD, `steps` steps.
+    Seed choice: for about a quarter of the seeds the reference's own fp32 run has a ReLU input within rounding of zero
+    whose mask differs from an fp64 run of the same model (gradients then move by 1e-3..1e-2, e.g. seeds 8, 10, 12, 17);
+    the HIP fp32 path, with another summation order, has its own such seeds (13, 16).  Seed 9 has none on either side
+    (reference fp32 vs fp64 1.6e-5, HIP vs reference 1.7e-5 over all 176 tensors), so it can carry a tight gradient bar."""
+    torch.manual_seed(0)
+    loss_mod.CLASS_NUMBER = ncls
+    m = Model.UNet_multitask(cin, ncls, feat, False)
+    out = dict(cin=cin, ncls=ncls, feat=feat, B=B, H=H, W=W, seed=seed)
+    for k, v in m.state_dict().items():
+        out["init_sig." + k] = sig(v.float())
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed))
+    x, lab1 = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
+    _, lab2 = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed + 100)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    m.train()
+    for step in range(steps):
+        o1, o2 = m(x)
+        loss = loss_mod.calc_loss(o1, lab1, loss_type="dice_bce_mc") + loss_mod.calc_loss(o2, lab2, loss_type="dice_bce_mc")
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out["logits1"], out["logits2"] = o1.detach().numpy(), o2.detach().numpy()
+            for k, p in m.named_parameters():
+                out["grad_sig." + k] = sig(p.grad)
+        out[f"loss{step}"] = loss.item()
+        opt.step()
+        if step in (0, steps - 1):
+            for k, v in m.state_dict().items():
+                out[f"after{step + 1}." + k] = sig(v.float())
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x)
+    out["eval_logits1"], out["eval_logits2"] = e1.numpy(), e2.numpy()
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out, **meta())
+    print(f"wrote {name}.npz loss0={out['loss0']:.6f}")
+
+
 def gen_trainer(Model, loss_mod, Trainer):
     """Config 1 plumbing: reference Trainer on CPU, UNet(1,2,8) to keep it fast, plus the
     same run's logged numbers.  (Config-1 proper, UNet(1,2,64) 256^2, is `unet_c1`.)"""
@@ -226,6 +267,8 @@ def main():
         if a.big:
             gen_unet_case(Model, loss_mod, "unet_c1", 1, 2, 64, 2, 256, 256, seed=7,
                           full_logits=False, steps=1)
+    if a.only in (None, "multitask"):
+        gen_unet_multitask(Model, loss_mod)
     if a.only in (None, "trainer"):
         gen_trainer(Model, loss_mod, Trainer)
     if a.only in (None, "transunet"):

@@ -46,11 +46,13 @@ class _TapeFunction(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, gout):
+    def backward(ctx, *gouts):
         tape = ctx.tape
         if tape is None or not tape.record:
             raise RuntimeError("backward called on a tape that was built without gradient recording")
-        tape.seed_grad_nchw(ctx.out_act, gout)
+        out_acts = ctx.out_act if isinstance(ctx.out_act, tuple) else (ctx.out_act,)
+        for a, g in zip(out_acts, gouts):            # several heads (UNet_multitask): one seed per output
+            tape.seed_grad_nchw(a, g)
         tape.backward()
         gin = [tape.input_grad_nchw(a) if need else None
                for a, need in zip(ctx.in_acts, ctx.needs_input_grad[3:3 + ctx.n_inputs])]
@@ -75,11 +77,13 @@ def _run_tape(module, inputs, build):
                       pack_cache=G.pack_cache_of(module))
         acts = [tape.input_nchw(x, needs_grad=need) for x, need in zip(inputs, in_needs)]
         out_act = build(tape, *acts)
-        if out_act.tx is None and out_act.raw.dtype == torch.float32:
-            out = tape.output_nchw_plain(out_act)
-        else:
+
+        def nchw(o):
+            if o.tx is None and o.raw.dtype == torch.float32:
+                return tape.output_nchw_plain(o)
             from umi import ops
-            out = ops.materialize_nchw(out_act.raw, out_act.tx)
+            return ops.materialize_nchw(o.raw, o.tx)
+        out = tuple(nchw(o) for o in out_act) if isinstance(out_act, tuple) else nchw(out_act)
         return tape, acts, out_act, out
 
     # grad mode is off inside Function.forward, so decide here whether to record the tape
@@ -116,6 +120,38 @@ def _build_up(t, x1, skip, cat, up):
     if up.dropout_flag:                            # cat -> Dropout(p) -> DoubleConv (reference Model.py:79-83)
         c = t.dropout(c, up.dropout.p)
     return _build_double_conv(t, c, up.conv)
+
+
+def _build_encoder(t, a, stages, f):
+    """inc + 4 x Down (reference Model.py:142-147).  Returns [(activation, concat buffer)] per level: every encoder output
+    but the deepest is written straight into the lower channel half of the concat buffer its decoder stage will read."""
+    N, dev = a.shape[0], a.raw.device
+    skips, cur = [], a
+    for lvl, st in enumerate(stages):
+        C = f * 2 ** lvl
+        h, w = (cur.shape[1], cur.shape[2]) if lvl == 0 else (cur.shape[1] // 2, cur.shape[2] // 2)
+        if lvl < len(stages) - 1:
+            cat = t.alloc(N, h, w, 2 * C, device=dev)
+            out = cat[..., :C]
+        else:
+            cat, out = None, None
+        cur = _build_double_conv(t, cur, st, out=out) if lvl == 0 else _build_down(t, cur, st, out=out)
+        skips.append((cur, cat))
+    return skips
+
+
+def _build_decoder(t, skips, ups, own_buffers=False):
+    """4 x Up from the deepest encoder output (reference Model.py:148-151).  own_buffers: a second decoder over the same
+    encoder (UNet_multitask) gets its own concat buffers, the skips are copied into them."""
+    y = skips[-1][0]
+    for i, up in enumerate(ups):
+        skip, cat = skips[len(skips) - 2 - i]
+        if own_buffers:
+            C = skip.shape[3]
+            cat = t.alloc(*skip.shape[:3], 2 * C, device=skip.raw.device)
+            skip = t.copy_into(skip, cat[..., :C])
+        y = _build_up(t, y, skip, cat, up)
+    return y
 
 
 class DoubleConv(_UmiModule):
@@ -230,31 +266,70 @@ class UNet(_UmiModule):
             raise ValueError(f"expected input [B,{self.n_channels},H,W], got {tuple(x.shape)}")
 
         def build(t, a):
-            N, H, W, _ = a.shape
-            f, dev = self.initial_feature_map, a.raw.device
-            skips = []
-            cur = a
-            stages = [self.inc, self.down1, self.down2, self.down3, self.down4]
-            for lvl, st in enumerate(stages):
-                C = f * 2 ** lvl
-                h, w = (cur.shape[1], cur.shape[2]) if lvl == 0 else (cur.shape[1] // 2, cur.shape[2] // 2)
-                if lvl < 4:          # encoder output doubles as the lower half of the decoder's concat buffer
-                    cat = t.alloc(N, h, w, 2 * C, device=dev)
-                    out = cat[..., :C]
-                else:
-                    cat, out = None, None
-                cur = _build_double_conv(t, cur, st, out=out) if lvl == 0 else _build_down(t, cur, st, out=out)
-                skips.append((cur, cat))
-            y = cur
-            for i, up in enumerate([self.up1, self.up2, self.up3, self.up4]):
-                skip, cat = skips[3 - i]
-                y = _build_up(t, y, skip, cat, up)
+            skips = _build_encoder(t, a, [self.inc, self.down1, self.down2, self.down3, self.down4],
+                                   self.initial_feature_map)
+            y = _build_decoder(t, skips, [self.up1, self.up2, self.up3, self.up4])
             return t.conv_bias(y, self.outc.conv.weight, self.outc.conv.bias, out_dtype=torch.float32)
 
         return _run_tape(self, [x], build)
 
     def use_checkpointing(self):
-        # Dead code in the reference (Model.py:155-165: torch.utils.checkpoint is a module, the call
-        # raises).  Saved activations are raw fp16 conv outputs here (~5.5 GB at B=16, 512^2 on a
-        # 288 GB part), so activation checkpointing is unnecessary.
-        raise NotImplementedError("use_checkpointing is broken in the reference and unnecessary here")
+        return _no_checkpointing()
+
+
+class UNet_multitask(_UmiModule):
+    """One encoder, two decoders, two logit maps -- reference Model.py:172-254 (same ctor, same state_dict keys
+    `up{1..4}_decod{1,2}`, `outc_decod{1,2}`; like the reference it builds Down/Up WITHOUT the dropout arguments).
+    Both decoders run on one tape: the encoder activations are computed once and their gradients are the sum over the
+    two decoders."""
+
+    def __init__(self, n_channels, n_classes, initial_feature_map=64, usa_cuda=True, dropout=False,
+                 dropout_p=0.5, *, compute_dtype=None):
+        super().__init__()
+        self.usa_cuda = usa_cuda
+        self.n_channels = {-2: 3, -1: 1}.get(n_channels, n_channels)
+        self.initial_feature_map = f = initial_feature_map
+        self.dropout = dropout
+        self.dropout_p = dropout_p
+        self._compute_dtype = compute_dtype
+
+        def stage(mod):
+            mod.apply(self.weights_init)
+            return mod
+        self.inc = stage(DoubleConv(self.n_channels, f))
+        self.down1 = stage(Down(f, f * 2))
+        self.down2 = stage(Down(f * 2, f * 4))
+        self.down3 = stage(Down(f * 4, f * 8))
+        self.down4 = stage(Down(f * 8, f * 16))
+        for d in (1, 2):                                 # reference order: all of decoder 1, then all of decoder 2
+            for i in range(1, 5):
+                setattr(self, f"up{i}_decod{d}", stage(Up(f * 2 ** (5 - i), f * 2 ** (4 - i))))
+            setattr(self, f"outc_decod{d}", stage(OutConv(f, n_classes)))
+
+    def weights_init(self, m):
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.n_channels:
+            raise ValueError(f"expected input [B,{self.n_channels},H,W], got {tuple(x.shape)}")
+
+        def build(t, a):
+            skips = _build_encoder(t, a, [self.inc, self.down1, self.down2, self.down3, self.down4],
+                                   self.initial_feature_map)
+            outs = []
+            for d in (1, 2):
+                y = _build_decoder(t, skips, [getattr(self, f"up{i}_decod{d}") for i in range(1, 5)],
+                                   own_buffers=(d == 2))
+                head = getattr(self, f"outc_decod{d}").conv
+                outs.append(t.conv_bias(y, head.weight, head.bias, out_dtype=torch.float32))
+            return tuple(outs)
+
+        return _run_tape(self, [x], build)
+
+
+def _no_checkpointing():
+    # Dead code in the reference (Model.py:155-165: torch.utils.checkpoint is a module, the call
+    # raises).  Saved activations are raw fp16 conv outputs here (~5.5 GB at B=16, 512^2 on a
+    # 288 GB part), so activation checkpointing is unnecessary.
+    raise NotImplementedError("use_checkpointing is broken in the reference and unnecessary here")

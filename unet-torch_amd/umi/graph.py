@@ -304,6 +304,19 @@ class Tape:
             self.steps.append(bwd)
         return o
 
+    def copy_into(self, a: Act, dest):
+        """A second home for `a` (same lazily-activated value, stored again in `dest`): lets one skip tensor sit in the
+        concat buffers of two decoders (reference Model.py:244-254, UNet_multitask).  Pure data movement."""
+        assert a.parts is None and tuple(dest.shape) == a.shape
+        dest.copy_(a.raw)
+        o = Act(dest, a.tx, needs_grad=a.needs_grad)
+        if self.record:
+            def bwd():
+                if o.grad is not None and _wants_grad(a):
+                    self._give(a, o.grad)
+            self.steps.append(bwd)
+        return o
+
     def concat(self, buf, acts):
         """`acts` were produced into consecutive channel slices of `buf`."""
         txs, parts, c0 = [], [], 0

@@ -1,0 +1,64 @@
+"""Inference entry on the MI355X: the steps either side of the network in the reference's evaluation scripts
+(test_mc3serousv5.py:100-127 `preprocess`, :877-887 forward -> softmax -> argmax -> uint8 mask), SURVEY 8(f) rank 4.
+
+    x = infer.preprocess(img)                 # HWC uint8 / float image (numpy or tensor) -> [1,C,H,W] fp32 on the device
+    mask = infer.predict_mask(model, x)       # eval-mode forward (BatchNorm from running statistics) + argmax, uint8 [N,H,W]
+
+The cubic `scipy.ndimage.zoom` resize of the reference (only taken when the image size differs from the network's input
+size) stays on the host and is not part of this module.  No CPU path: the arithmetic is libunetmi kernels.
+"""
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+
+
+def preprocess(img, reverse_channels=None):
+    """Per-channel z-normalisation of one image, HWC (or HW) -> [1,C,H,W] fp32 (reference `preprocess`: mean / np.std over
+    H,W in fp64; 3-channel images are also flipped BGR -> RGB, `reverse_channels` defaults to that rule)."""
+    if isinstance(img, np.ndarray):
+        img = torch.from_numpy(np.ascontiguousarray(img))
+    if img.dim() == 2:
+        img = img.unsqueeze(-1)
+    if img.dim() != 3 or img.shape[2] > 4:
+        raise ValueError(f"expected an HW or HWC image with at most 4 channels, got {tuple(img.shape)}")
+    if img.dtype not in (torch.uint8, torch.float32):
+        img = img.float()
+    img = img.contiguous().to("cuda", non_blocking=True)
+    H, W, C = img.shape
+    if reverse_channels is None:
+        reverse_channels = C == 3
+    out = torch.empty((1, C, H, W), dtype=torch.float32, device=img.device)
+    nbytes = L.fn("umi_znorm_ws_bytes")()
+    ws = ops.workspace(nbytes, img.device)
+    L.check(L.fn("umi_znorm_hwc")(img.data_ptr(), 0 if img.dtype == torch.uint8 else 1, out.data_ptr(), H * W, C,
+                                  int(bool(reverse_channels)), ws.data_ptr(), nbytes, ops._stream()), "umi_znorm_hwc")
+    return out
+
+
+def argmax_mask(logits):
+    """[N,C,H,W] fp32 logits -> uint8 [N,H,W] class mask (== softmax(dim=1).argmax(dim=1), first maximum wins)."""
+    ops._need_cuda(logits)
+    if logits.dim() != 4 or logits.dtype != torch.float32:
+        raise ValueError("argmax_mask expects fp32 logits [N,C,H,W]")
+    logits = logits.contiguous()
+    N, C, H, W = logits.shape
+    mask = torch.empty((N, H, W), dtype=torch.uint8, device=logits.device)
+    L.check(L.fn("umi_argmax_mask")(logits.data_ptr(), mask.data_ptr(), N, C, H * W, ops._stream()), "umi_argmax_mask")
+    return mask
+
+
+@torch.no_grad()
+def predict_mask(model, x):
+    """Reference evaluation step (test_mc3serousv5.py:879-885): eval-mode forward, softmax, argmax -> uint8 mask.  The
+    model's kernel-layout weight copies are cached between calls (ops.PackCache), so a loop over images packs once."""
+    was_training = model.training
+    model.eval()
+    try:
+        out = model(x.to("cuda"))
+        if isinstance(out, tuple):
+            return tuple(argmax_mask(o) for o in out)
+        return argmax_mask(out)
+    finally:
+        model.train(was_training)
