@@ -246,6 +246,21 @@ int umi_pack_kn_multi(const void* descs, int n_desc, int total_blocks, int dtype
  *   (BGR -> RGB); mean and population std per channel in fp64 (numpy semantics), two-pass variance.
  * umi_argmax_mask (test_mc3serousv5.py:883-885 softmax -> argmax -> uint8): mask[n][p] = argmax_c logits[n][c][p], first
  *   maximum wins; softmax is monotone and therefore skipped. */
+/* Additive attention gate of UNet_attention (reference Model.py:265-305, Attention_block.forward :297-305); the 1x1
+ * convolutions and BatchNorms of the block go through umi_conv_fwd / umi_bn_finalize, these are the fused elementwise steps:
+ *   add2_relu: y = max(txa(a) + txb(b), 0)   (E = relu(Q1 + X1), Model.py:302);  bwd: da = db = dy * [y > 0]
+ *   gate:      y[m][c] = txx(x[m][c]) * sigmoid(txp(p[m]))   (x * A, Model.py:303-304; p has ONE channel, txp one row)
+ *              bwd: dx = dy * A,  dp[m] = A (1 - A) * sum_c dy[m][c] * txx(x[m][c])   (gradient w.r.t. txp(p), i.e. the
+ *              BatchNorm output before the sigmoid). */
+int umi_add2_relu_fwd(const void* a, int lda, const void* txa, const void* b, int ldb, const void* txb, void* y, int ldy,
+                      long M, int C, int dtype, umi_stream_t stream);
+int umi_add2_relu_bwd(const void* dy, int lddy, const void* y, int ldy, void* da, int ldda, void* db, int lddb, long M, int C,
+                      int dtype, umi_stream_t stream);
+int umi_gate_fwd(const void* x, int ldx, const void* txx, const void* p, const void* txp, void* y, int ldy, long M, int C,
+                 int dtype, umi_stream_t stream);
+int umi_gate_bwd(const void* dy, int lddy, const void* x, int ldx, const void* txx, const void* p, const void* txp, void* dx,
+                 int lddx, void* dp, long M, int C, int dtype, umi_stream_t stream);
+
 size_t umi_znorm_ws_bytes(void);
 int umi_znorm_hwc(const void* img, int src_dtype, float* out_chw, long HW, int C, int reverse_channels, void* ws,
                   size_t ws_bytes, umi_stream_t stream);

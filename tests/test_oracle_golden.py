@@ -118,3 +118,34 @@ def test_unet_multitask_matches_reference(golden_dir):
         e1, e2 = m(x)
     _close(e1.numpy(), g["eval_logits1"], rtol=1e-4, atol=1e-5)
     _close(e2.numpy(), g["eval_logits2"], rtol=1e-4, atol=1e-5)
+
+
+def test_unet_attention_matches_reference(golden_dir):
+    """oracle restatement of UNet_attention / Attention_block (reference Model.py:265-391) against
+    the reference's own outputs (same state_dict keys in the same order, logits, gradients, 3 SGD steps, eval logits)."""
+    g = np.load(os.path.join(golden_dir, "unet_attention_1_2_8.npz"))
+    cin, ncls, feat = int(g["cin"]), int(g["ncls"]), int(g["feat"])
+    B, H, W, seed = int(g["B"]), int(g["H"]), int(g["W"]), int(g["seed"])
+    m = ref_unet.RefUNetAttention(cin, ncls, feat, False)
+    assert [k[len("init_sig."):] for k in g.files if k.startswith("init_sig.")] == list(m.state_dict().keys())
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed))
+    x, lab = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    m.train()
+    for step in range(3):
+        logits = m(x)
+        loss = ref_unet.dice_bce_mc(logits, lab, ncls)
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            _close(logits.detach().numpy(), g["logits"])
+            for k, p in m.named_parameters():
+                if float(g["grad_sig." + k][0]) > 1e-7:        # conv biases in front of a BatchNorm: gradient is rounding noise
+                    _sig_close(sig(p.grad), g["grad_sig." + k], rtol=5e-4)
+        assert abs(loss.item() - float(g[f"loss{step}"])) < 2e-6
+        opt.step()
+    for k, v in m.state_dict().items():
+        _sig_close(sig(v.float()), g["after3." + k], rtol=5e-4)
+    m.eval()
+    with torch.no_grad():
+        _close(m(x).numpy(), g["eval_logits"], rtol=1e-4, atol=1e-5)

@@ -8,7 +8,7 @@ module level but never touch on the hot path: `torchvision`
 oracle/recipe.py (build-owned seeds), so only numeric *outputs* of the reference are
 serialised.  /root/reference never travels to the GPU box; these fixtures do.
 
-Usage:  python tools/gen_golden.py [--only unet|blocks|multitask|trainer|transunet] [--big]
+Usage:  python tools/gen_golden.py [--only unet|blocks|multitask|attention|trainer|transunet] [--big]
 """
 import argparse
 import os
@@ -221,6 +221,40 @@ def gen_unet_multitask(Model, loss_mod, name="unet_multitask_1_2_8", cin=1, ncls
     print(f"wrote {name}.npz loss0={out['loss0']:.6f}")
 
 
+def gen_unet_attention(Model, loss_mod, name="unet_attention_1_2_8", cin=1, ncls=2, feat=8, B=2, H=64, W=64, seed=15,
+                       steps=3):
+    """Reference UNet_attention (Model.py:308-391), dice_bce_mc loss, SGD, `steps` steps.  (Seed: see gen_unet_multitask.)"""
+    torch.manual_seed(0)
+    loss_mod.CLASS_NUMBER = ncls
+    m = Model.UNet_attention(cin, ncls, feat, False)
+    out = dict(cin=cin, ncls=ncls, feat=feat, B=B, H=H, W=W, seed=seed)
+    for k, v in m.state_dict().items():
+        out["init_sig." + k] = sig(v.float())
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed))
+    x, lab = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    m.train()
+    for step in range(steps):
+        logits = m(x)
+        loss = loss_mod.calc_loss(logits, lab, loss_type="dice_bce_mc")
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out["logits"] = logits.detach().numpy()
+            for k, p in m.named_parameters():
+                out["grad_sig." + k] = sig(p.grad)
+        out[f"loss{step}"] = loss.item()
+        opt.step()
+        if step in (0, steps - 1):
+            for k, v in m.state_dict().items():
+                out[f"after{step + 1}." + k] = sig(v.float())
+    m.eval()
+    with torch.no_grad():
+        out["eval_logits"] = m(x).numpy()
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out, **meta())
+    print(f"wrote {name}.npz loss0={out['loss0']:.6f}")
+
+
 def gen_trainer(Model, loss_mod, Trainer):
     """Config 1 plumbing: reference Trainer on CPU, UNet(1,2,8) to keep it fast, plus the
     same run's logged numbers.  (Config-1 proper, UNet(1,2,64) 256^2, is `unet_c1`.)"""
@@ -269,6 +303,8 @@ def main():
                           full_logits=False, steps=1)
     if a.only in (None, "multitask"):
         gen_unet_multitask(Model, loss_mod)
+    if a.only in (None, "attention"):
+        gen_unet_attention(Model, loss_mod)
     if a.only in (None, "trainer"):
         gen_trainer(Model, loss_mod, Trainer)
     if a.only in (None, "transunet"):

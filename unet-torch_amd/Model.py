@@ -122,15 +122,16 @@ def _build_up(t, x1, skip, cat, up):
     return _build_double_conv(t, c, up.conv)
 
 
-def _build_encoder(t, a, stages, f):
+def _build_encoder(t, a, stages, f, into_concat=True):
     """inc + 4 x Down (reference Model.py:142-147).  Returns [(activation, concat buffer)] per level: every encoder output
-    but the deepest is written straight into the lower channel half of the concat buffer its decoder stage will read."""
+    but the deepest is written straight into the lower channel half of the concat buffer its decoder stage will read
+    (into_concat=False: plain outputs, for UNet_attention whose decoder concatenates the GATED skip instead)."""
     N, dev = a.shape[0], a.raw.device
     skips, cur = [], a
     for lvl, st in enumerate(stages):
         C = f * 2 ** lvl
         h, w = (cur.shape[1], cur.shape[2]) if lvl == 0 else (cur.shape[1] // 2, cur.shape[2] // 2)
-        if lvl < len(stages) - 1:
+        if into_concat and lvl < len(stages) - 1:
             cat = t.alloc(N, h, w, 2 * C, device=dev)
             out = cat[..., :C]
         else:
@@ -326,6 +327,103 @@ class UNet_multitask(_UmiModule):
             return tuple(outs)
 
         return _run_tape(self, [x], build)
+
+
+def _build_attention(t, q, x, ab, dest):
+    """Attention_block.forward (reference Model.py:297-305): dest <- x * sigmoid(BN(psi(relu(BN(Wq up(q)) + BN(Wx x)))))."""
+    N, h, w, Cq = q.shape
+    if (2 * h, 2 * w) != tuple(x.shape[1:3]):
+        raise ValueError(f"attention gate: upsampled query {2 * h}x{2 * w} != skip {x.shape[1]}x{x.shape[2]} "
+                         "(the reference's Q1 + X1 fails the same way)")
+    qu = t.conv_transpose2x2(q, ab.up.weight, ab.up.bias, t.alloc(N, 2 * h, 2 * w, Cq, device=q.raw.device))
+    q1 = t.conv_bn(qu, ab.W_q[0].weight, ab.W_q[1], pad=0, relu=False, bias=ab.W_q[0].bias)
+    x1 = t.conv_bn(x, ab.W_x[0].weight, ab.W_x[1], pad=0, relu=False, bias=ab.W_x[0].bias)
+    e = t.add_relu(q1, x1)
+    p = t.conv_bn(e, ab.psi[0].weight, ab.psi[1], pad=0, relu=False, bias=ab.psi[0].bias)
+    return t.gate(x, p, dest)
+
+
+class Attention_block(_UmiModule):
+    """Additive attention gate -- reference Model.py:265-305 (same ctor, same state_dict keys W_q.*, up.*, W_x.*, psi.*).
+    The nn.Sigmoid / nn.ReLU children only keep the reference's module indices; the arithmetic is libunetmi kernels."""
+
+    def __init__(self, C_q, C_x, C_hidden, *, compute_dtype=None):
+        super().__init__()
+        self.W_q = nn.Sequential(nn.Conv2d(C_q, C_hidden, kernel_size=1, stride=1, padding=0, bias=True),
+                                 nn.BatchNorm2d(C_hidden))
+        self.up = nn.ConvTranspose2d(C_q, C_q, kernel_size=2, stride=2)
+        self.W_x = nn.Sequential(nn.Conv2d(C_x, C_hidden, kernel_size=1, stride=1, padding=0, bias=True),
+                                 nn.BatchNorm2d(C_hidden))
+        self.psi = nn.Sequential(nn.Conv2d(C_hidden, 1, kernel_size=1, stride=1, padding=0, bias=True),
+                                 nn.BatchNorm2d(1), nn.Sigmoid())
+        self.relu = nn.ReLU(inplace=True)
+        self._compute_dtype = compute_dtype
+
+    def forward(self, q, x):
+        def build(t, aq, ax):
+            N, H, W, C = ax.shape
+            return _build_attention(t, aq, ax, self, t.alloc(N, H, W, C, device=ax.raw.device))
+        return _run_tape(self, [q, x], build)
+
+
+class UNet_attention(_UmiModule):
+    """Attention U-Net -- reference Model.py:308-391: every skip connection is gated by the decoder state below it
+    (attribute names `attenion{4..1}` as in the reference, typo included, so checkpoints load)."""
+
+    def __init__(self, n_channels, n_classes, initial_feature_map=64, usa_cuda=True, dropout=False,
+                 dropout_p=0.5, *, compute_dtype=None):
+        super().__init__()
+        self.usa_cuda = usa_cuda
+        self.n_channels = {-2: 3, -1: 1}.get(n_channels, n_channels)
+        self.initial_feature_map = f = initial_feature_map
+        self.dropout = dropout
+        self.dropout_p = dropout_p
+        self._compute_dtype = compute_dtype
+
+        def stage(mod):
+            mod.apply(self.weights_init)
+            return mod
+        self.inc = stage(DoubleConv(self.n_channels, f))
+        self.down1 = stage(Down(f, f * 2, dropout, dropout_p))
+        self.down2 = stage(Down(f * 2, f * 4, dropout, dropout_p))
+        self.down3 = stage(Down(f * 4, f * 8, dropout, dropout_p))
+        self.down4 = stage(Down(f * 8, f * 16, dropout, dropout_p))
+        # attention gates keep torch's default init (the reference never applies weights_init to them, Model.py:339-355)
+        self.attenion4 = Attention_block(C_q=f * 16, C_x=f * 8, C_hidden=f * 4)
+        self.attenion3 = Attention_block(C_q=f * 8, C_x=f * 4, C_hidden=f * 2)
+        self.attenion2 = Attention_block(C_q=f * 4, C_x=f * 2, C_hidden=f)
+        self.attenion1 = Attention_block(C_q=f * 2, C_x=f, C_hidden=int(f / 2))
+        self.up1 = stage(Up(f * 16, f * 8, dropout, dropout_p))
+        self.up2 = stage(Up(f * 8, f * 4, dropout, dropout_p))
+        self.up3 = stage(Up(f * 4, f * 2, dropout, dropout_p))
+        self.up4 = stage(Up(f * 2, f, dropout, dropout_p))
+        self.outc = stage(OutConv(f, n_classes))
+
+    def weights_init(self, m):
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.n_channels:
+            raise ValueError(f"expected input [B,{self.n_channels},H,W], got {tuple(x.shape)}")
+
+        def build(t, a):
+            skips = _build_encoder(t, a, [self.inc, self.down1, self.down2, self.down3, self.down4],
+                                   self.initial_feature_map, into_concat=False)
+            y = skips[-1][0]
+            gates = [self.attenion4, self.attenion3, self.attenion2, self.attenion1]
+            for i, (att, up) in enumerate(zip(gates, [self.up1, self.up2, self.up3, self.up4])):
+                skip = skips[3 - i][0]
+                C = skip.shape[3]
+                cat = t.alloc(*skip.shape[:3], 2 * C, device=skip.raw.device)
+                gated = _build_attention(t, y, skip, att, cat[..., :C])       # written into the decoder's concat buffer
+                y = _build_up(t, y, gated, cat, up)
+            return t.conv_bias(y, self.outc.conv.weight, self.outc.conv.bias, out_dtype=torch.float32)
+
+        return _run_tape(self, [x], build)
+
+    def use_checkpointing(self):
+        return _no_checkpointing()
 
 
 def _no_checkpointing():

@@ -122,10 +122,14 @@ class Tape:
         return a
 
     # ---- ops ---------------------------------------------------------------------------
-    def conv_bn(self, a: Act, weight, bn, out=None, stride=1, pad=1, input_exclusive=False):
+    def conv_bn(self, a: Act, weight, bn, out=None, stride=1, pad=1, input_exclusive=False, relu=True, bias=None):
         """Conv2d(bias=False) -> BatchNorm2d -> ReLU, the last two deferred to the consumer.
         input_exclusive: this conv is the ONLY consumer of `a` (DoubleConv's second conv): its data-gradient kernel may then
-        also emit stage 1 of `a`'s BatchNorm backward reduction (one pass over the gradient tensor less)."""
+        also emit stage 1 of `a`'s BatchNorm backward reduction (one pass over the gradient tensor less).
+        relu=False: BatchNorm only (the W_q / W_x / psi branches of the attention gate, reference Model.py:268-289).
+        bias: the conv's bias when a BatchNorm follows it (same place).  In training mode BatchNorm subtracts it again, so
+        it is never added to the stored tensor: it only shifts running_mean, and its gradient is zero; in eval mode it is
+        folded into the consumer transform."""
         Co, Ci, R, S = weight.shape
         N, H, W, Ca = a.shape
         assert Ca == Ci, f"conv expects {Ci} input channels, got {Ca}"
@@ -133,8 +137,10 @@ class Tape:
         if out is None:
             out = self.alloc(N, Ho, Wo, Co, device=a.raw.device)
         wf = weight.detach().float()
+        # the pointwise matrix-core kernel has no statistics epilogue: 1x1 convs that feed a BatchNorm take the generic one
+        flags = L.CONV_FORCE_GENERIC if (self.training and (R, S) == (1, 1)) else 0
         part = ops.conv_fwd(a.raw, a.tx, lambda lay: self._pack("conv_fwd", weight, wf, bool(lay)), None, out,
-                            R, S, stride, pad, want_stats=self.training)
+                            R, S, stride, pad, want_stats=self.training, flags=flags)
         if self.training:
             mom = bn.momentum if bn.momentum is not None else 0.1
             tx, rstd = ops.bn_finalize(part, Co, N * Ho * Wo, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
@@ -142,8 +148,14 @@ class Tape:
                                        bn.running_var if bn.track_running_stats else None)
             if bn.track_running_stats and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
+            if bias is not None and bn.track_running_stats:
+                bn.running_mean.add_(bias.detach().float(), alpha=mom)      # batch mean of (y + bias) = mean(y) + bias
         else:
             tx, rstd = ops.eval_bn_tx(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+            if bias is not None:
+                tx[:, 2] += tx[:, 1] * bias.detach().float()
+        if not relu:
+            tx[:, 3] = ops.NEG_INF
         o = Act(out, tx)
         o.bn_rstd = rstd
         if self.record:
@@ -167,6 +179,10 @@ class Tape:
                 gw = self._new_pgrad(weight)
                 ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad)
                 self._set_pgrad(weight, gw)
+                if bias is not None:
+                    gb = self._new_pgrad(bias)
+                    gb.zero_()                       # d/d bias of BatchNorm(conv + bias) vanishes identically
+                    self._set_pgrad(bias, gb)
                 if _wants_grad(a):
                     if stride != 1:
                         raise NotImplementedError("dgrad for strided conv_bn")
@@ -314,6 +330,43 @@ class Tape:
             def bwd():
                 if o.grad is not None and _wants_grad(a):
                     self._give(a, o.grad)
+            self.steps.append(bwd)
+        return o
+
+    def add_relu(self, a: Act, b: Act):
+        """relu(a + b) of two lazily-activated values, stored activated (attention gate, reference Model.py:302)."""
+        N, H, W, C = a.shape
+        assert b.shape == a.shape
+        out = self.alloc(N, H, W, C, device=a.raw.device)
+        ops.add2_relu(a.raw, a.tx, b.raw, b.tx, out)
+        o = Act(out, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                da = self.alloc(N, H, W, C, device=out.device)      # two tensors: each branch's BatchNorm backward
+                db = self.alloc(N, H, W, C, device=out.device)      # rewrites its gradient in place
+                ops.add2_relu_bwd(o.grad, out, da, db)
+                self._give(a, da)
+                self._give(b, db)
+            self.steps.append(bwd)
+        return o
+
+    def gate(self, x: Act, p: Act, dest):
+        """dest <- x * sigmoid(p), p one channel broadcast over x's channels (reference Model.py:303-304); stored activated."""
+        N, H, W, C = x.shape
+        assert p.shape == (N, H, W, 1) and tuple(dest.shape) == x.shape
+        ops.gate(x.raw, x.tx, p.raw, p.tx, dest)
+        o = Act(dest, None)
+        if self.record:
+            def bwd():
+                if o.grad is None:
+                    return
+                dx = self.alloc(N, H, W, C, device=dest.device)
+                dp = self.alloc(N, H, W, 1, device=dest.device)
+                ops.gate_bwd(o.grad, x.raw, x.tx, p.raw, p.tx, dx, dp)
+                self._give(x, dx)
+                self._give(p, dp)
             self.steps.append(bwd)
         return o
 

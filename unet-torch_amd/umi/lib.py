@@ -100,6 +100,13 @@ SIGNATURES = {
                                      c_void_p]),
     "umi_pack_block_elems": (c_int, []),
     "umi_pack_kn_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "umi_add2_relu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_long, c_int, c_int,
+                                  c_void_p]),
+    "umi_add2_relu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_int,
+                                  c_void_p]),
+    "umi_gate_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
+    "umi_gate_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                             c_long, c_int, c_int, c_void_p]),
     "umi_znorm_ws_bytes": (c_size_t, []),
     "umi_znorm_hwc": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "umi_argmax_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p]),

@@ -372,6 +372,37 @@ def colsum(x, out, out_scale):
                                ws.numel(), _stream()), "umi_colsum")
 
 
+def add2_relu(a, txa, b, txb, y):
+    """y <- max(txa(a) + txb(b), 0)  (attention gate, reference Model.py:302)."""
+    N, H, W, C, lda = _nhwc(a)
+    _, _, _, _, ldb = _nhwc(b)
+    _, _, _, _, ldy = _nhwc(y)
+    assert a.shape == b.shape == y.shape
+    L.check(L.fn("umi_add2_relu_fwd")(a.data_ptr(), lda, _ptr(txa), b.data_ptr(), ldb, _ptr(txb), y.data_ptr(), ldy,
+                                      N * H * W, C, _dt(a), _stream()), "umi_add2_relu_fwd")
+
+
+def add2_relu_bwd(dy, y, da, db):
+    N, H, W, C, lddy = _nhwc(dy)
+    L.check(L.fn("umi_add2_relu_bwd")(dy.data_ptr(), lddy, y.data_ptr(), _nhwc(y)[4], da.data_ptr(), _nhwc(da)[4],
+                                      db.data_ptr(), _nhwc(db)[4], N * H * W, C, _dt(dy), _stream()), "umi_add2_relu_bwd")
+
+
+def gate(x, txx, p, txp, y):
+    """y <- txx(x) * sigmoid(txp(p)), p: [N,H,W,1] (reference Model.py:303-304)."""
+    N, H, W, C, ldx = _nhwc(x)
+    assert tuple(p.shape) == (N, H, W, 1) and p.is_contiguous() and y.shape == x.shape
+    L.check(L.fn("umi_gate_fwd")(x.data_ptr(), ldx, _ptr(txx), p.data_ptr(), _ptr(txp), y.data_ptr(), _nhwc(y)[4],
+                                 N * H * W, C, _dt(x), _stream()), "umi_gate_fwd")
+
+
+def gate_bwd(dy, x, txx, p, txp, dx, dp):
+    N, H, W, C, ldx = _nhwc(x)
+    assert dp.is_contiguous() and tuple(dp.shape) == (N, H, W, 1)
+    L.check(L.fn("umi_gate_bwd")(dy.data_ptr(), _nhwc(dy)[4], x.data_ptr(), ldx, _ptr(txx), p.data_ptr(), _ptr(txp),
+                                 dx.data_ptr(), _nhwc(dx)[4], dp.data_ptr(), N * H * W, C, _dt(x), _stream()), "umi_gate_bwd")
+
+
 def materialize_nchw(x, tx):
     N, H, W, C, ldx = _nhwc(x)
     y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
