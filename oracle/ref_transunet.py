@@ -55,6 +55,8 @@ def _bias_for(fan_in):
 
 
 class RefTransUNet(nn.Module):
+    HEADS = (("decoder", "segmentation_head"),)                  # (decoder attribute, head attribute) per output
+
     def __init__(self, cfg, img_size=224):
         super().__init__()
         self.cfg, self.img_size = dict(cfg), img_size
@@ -112,14 +114,15 @@ class RefTransUNet(nn.Module):
             skip = [0, 0, 0, 0]
         dec = list(cfg["decoder_channels"])
         ins = [512] + dec[:-1]
-        self._bn(("decoder.conv_more", 512, hid))
-        self.dec_blocks = []
-        for i, (ci, co, sk) in enumerate(zip(ins, dec, skip)):
-            self._bn((f"decoder.blocks.{i}.conv1", co, ci + sk))
-            self._bn((f"decoder.blocks.{i}.conv2", co, co))
-            self.dec_blocks.append((f"decoder.blocks.{i}", sk))
-        _param(self, "segmentation_head.0.weight", (cfg["n_classes"], dec[-1], 3, 3), _conv_w)
-        _param(self, "segmentation_head.0.bias", (cfg["n_classes"],), _bias_for(dec[-1] * 9))
+        self.dec_blocks = [(f"blocks.{i}", sk) for i, sk in enumerate(skip)]
+        for dname, _ in self.HEADS:                              # all decoders first, then all heads (reference order)
+            self._bn((dname + ".conv_more", 512, hid))
+            for i, (ci, co, sk) in enumerate(zip(ins, dec, skip)):
+                self._bn((f"{dname}.blocks.{i}.conv1", co, ci + sk))
+                self._bn((f"{dname}.blocks.{i}.conv2", co, co))
+        for _, hname in self.HEADS:
+            _param(self, hname + ".0.weight", (cfg["n_classes"], dec[-1], 3, 3), _conv_w)
+            _param(self, hname + ".0.bias", (cfg["n_classes"],), _bias_for(dec[-1] * 9))
 
     def _bn(self, spec):
         path, co, ci = spec
@@ -217,13 +220,26 @@ class RefTransUNet(nn.Module):
         h = t.flatten(2).transpose(-1, -2) + emb.position_embeddings
         h = F.dropout(h, self.cfg["dropout_rate"], self.training)
         h = self.encoder(h)
-        y = h.permute(0, 2, 1).contiguous().view(B, C, gh, gw)
-        y = self._bn_relu_conv(y, "decoder.conv_more")
-        for i, (path, sk) in enumerate(self.dec_blocks):
-            y = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=True)
-            if sk and i < self.cfg["n_skip"]:
-                y = torch.cat([y, feats[i]], dim=1)
-            y = self._bn_relu_conv(y, path + ".conv1")
-            y = self._bn_relu_conv(y, path + ".conv2")
-        sh = getattr(self.segmentation_head, "0")
-        return F.conv2d(y, sh.weight, sh.bias, 1, 1)
+        tokens = h.permute(0, 2, 1).contiguous().view(B, C, gh, gw)
+        outs = []
+        for dname, hname in self.HEADS:                          # vit_seg_modeling.py:389-392 / :468-476 (shared encoder)
+            y = self._bn_relu_conv(tokens, dname + ".conv_more")
+            for i, (path, sk) in enumerate(self.dec_blocks):
+                y = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=True)
+                if sk and i < self.cfg["n_skip"]:
+                    y = torch.cat([y, feats[i]], dim=1)
+                y = self._bn_relu_conv(y, f"{dname}.{path}.conv1")
+                y = self._bn_relu_conv(y, f"{dname}.{path}.conv2")
+            sh = getattr(getattr(self, hname), "0")
+            outs.append(F.conv2d(y, sh.weight, sh.bias, 1, 1))
+        return outs[0] if len(outs) == 1 else tuple(outs)
+
+
+class RefTransUNetMultitask(RefTransUNet):
+    """Reference VisionTransformerMultitask (vit_seg_modeling.py:444-476): one encoder, two CUP decoders, two heads."""
+    HEADS = (("decoder1", "segmentation_head1"), ("decoder2", "segmentation_head2"))
+
+
+class RefTransUNetMultitaskEM(RefTransUNet):
+    """Reference VisionTransformerMultitaskEM (vit_seg_modeling.py:524-590): six decoders / heads over one encoder."""
+    HEADS = tuple((f"decoder{i}", f"segmentation_head{i}") for i in range(1, 7))

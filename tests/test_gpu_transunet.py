@@ -150,3 +150,44 @@ def test_transunet_small_fp16_runs_close(golden_dir):
         if rp.numel() >= 4096 and rp.grad.norm() > 1e-8:
             c = (p.grad.cpu().flatten().double() @ rp.grad.flatten().double() / (p.grad.norm().cpu().double() * rp.grad.norm().double())).item()
             assert c > 0.9, (k, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,pcls,rcls", [
+    ("transunet_small_multitask", "VisionTransformerMultitask", "RefTransUNetMultitask"),
+    ("transunet_small_multitask_em", "VisionTransformerMultitaskEM", "RefTransUNetMultitaskEM")])
+def test_transunet_multitask_fp32_parity(golden_dir, name, pcls, rcls):
+    """the multitask TransUNets (one encoder, 2 / 6 decoders on one tape) against the REFERENCE's logits
+    of every head (fixture) and the oracle's gradients (encoder gradients = sum over the decoders)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    import loss as L
+    from TransUnet import vit_seg_modeling as vsm
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = ref_transunet.small_config(2)
+    img, B, cin, seed = int(g["img"]), int(g["B"]), int(g["cin"]), int(g["seed"])
+    ref = getattr(ref_transunet, rcls)(cfg, img)
+    ref.load_state_dict(recipe.fill_state_dict(ref.state_dict(), seed=seed, negative_gamma=False))
+    x, _ = recipe.synthetic_batch(B, cin, img, img, 2, seed=seed)
+    L.CLASS_NUMBER = 2
+    m = getattr(vsm, pcls)(product_config(cfg, img), img_size=img, num_classes=2, compute_dtype="fp32")
+    assert list(m.state_dict().keys()) == g["keys"].tolist()
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).train()
+    outs = m(x.to(DEV))
+    assert isinstance(outs, tuple) and len(outs) == len(ref.HEADS)
+    labs = [recipe.synthetic_batch(B, cin, img, img, 2, seed=seed + 100 * i)[1] for i in range(len(outs))]
+    loss = sum(L.calc_loss(o, l.to(DEV), loss_type="dice_bce_mc") for o, l in zip(outs, labs))
+    loss.backward()
+    for i, o in enumerate(outs):
+        gl = g[f"logits{i + 1}"]
+        np.testing.assert_allclose(o.detach().cpu().numpy(), gl, rtol=1e-4, atol=1e-4 * float(np.abs(gl).max()))
+    assert abs(loss.item() - float(g["loss0"])) < 1e-4
+    ref.train()
+    sum(ref_unet.dice_bce_mc(o, l, 2) for o, l in zip(ref(x), labs)).backward()
+    worst = ("", 0.0)
+    for (k, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, k
+        e = (p.grad.detach().double().cpu() - rp.grad.double()).norm().item() / (rp.grad.double().norm().item() + 1e-6 / 3e-3)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    assert worst[1] < 3e-3, worst

@@ -55,3 +55,29 @@ def test_r50_vit_b16_parameter_count():
     m = ref_transunet.RefTransUNet(ref_transunet.r50_vit_b16_config(2), 224)
     assert sum(p.numel() for p in m.parameters()) == 105_276_066
     assert len(m.state_dict()) == 409
+
+
+@pytest.mark.parametrize("name,cls", [("transunet_small_multitask", "RefTransUNetMultitask"),
+                                      ("transunet_small_multitask_em", "RefTransUNetMultitaskEM")])
+def test_transunet_multitask_oracle_matches_reference(golden_dir, name, cls):
+    """VisionTransformerMultitask / ...EM (reference vit_seg_modeling.py:444-638): shared encoder, 2 / 6
+    CUP decoders and heads.  Same state_dict keys in the same order, logits of every head, loss, gradients."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = ref_transunet.small_config(2)
+    img, B, cin, seed = int(g["img"]), int(g["B"]), int(g["cin"]), int(g["seed"])
+    m = getattr(ref_transunet, cls)(cfg, img)
+    assert list(m.state_dict().keys()) == g["keys"].tolist()
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed, negative_gamma=False))
+    x, _ = recipe.synthetic_batch(B, cin, img, img, 2, seed=seed)
+    m.train()
+    outs = m(x)
+    labs = [recipe.synthetic_batch(B, cin, img, img, 2, seed=seed + 100 * i)[1] for i in range(len(outs))]
+    loss = sum(ref_unet.dice_bce_mc(o, l, 2) for o, l in zip(outs, labs))
+    loss.backward()
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), g[f"logits{i + 1}"], rtol=1e-3, atol=2e-5)
+    assert abs(loss.item() - float(g["loss0"])) < 2e-5
+    for k, p in m.named_parameters():
+        if "position_embeddings" in k and float(g["grad_sig." + k][0]) == 0:
+            continue
+        _sig_close(sig(p.grad), g["grad_sig." + k], rtol=2e-3)

@@ -62,11 +62,39 @@ def _case(vsm, loss_mod, sig, meta, GOLD, name, cfg, img, B, cin, seed, full):
     print(f"wrote {name}.npz keys={out['n_keys']} loss0={out['loss0']:.6f}")
 
 
+def _case_multitask(vsm, loss_mod, sig, meta, GOLD, name, cls_name, cfg, img, B, cin, seed):
+    """VisionTransformerMultitask / ...EM (reference vit_seg_modeling.py:444-638), loss = sum of the heads' dice_bce_mc
+    losses (Trainer.py:885-890 for two heads).  Seed chosen free of fp32 ReLU near-ties (see gen_golden.gen_unet_multitask)."""
+    torch.manual_seed(0)
+    loss_mod.CLASS_NUMBER = cfg["n_classes"]
+    m = getattr(vsm, cls_name)(_ref_config(cfg, img), img_size=img, num_classes=cfg["n_classes"])
+    out = dict(img=img, B=B, cin=cin, seed=seed, n_keys=len(m.state_dict()))
+    out["keys"] = np.array(list(m.state_dict().keys()))
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed, negative_gamma=False))
+    x, _ = recipe.synthetic_batch(B, cin, img, img, cfg["n_classes"], seed=seed)
+    m.train()
+    logits = m(x)
+    labs = [recipe.synthetic_batch(B, cin, img, img, cfg["n_classes"], seed=seed + 100 * i)[1] for i in range(len(logits))]
+    loss = sum(loss_mod.calc_loss(o, l, loss_type="dice_bce_mc") for o, l in zip(logits, labs))
+    loss.backward()
+    out["loss0"] = loss.item()
+    for i, o in enumerate(logits):
+        out[f"logits{i + 1}"] = o.detach().numpy()
+    for k, p in m.named_parameters():
+        out["grad_sig." + k] = sig(p.grad)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out, **meta())
+    print(f"wrote {name}.npz keys={out['n_keys']} loss0={out['loss0']:.6f}")
+
+
 def run(import_reference, sig, meta, GOLD, big=False):
     _, loss_mod, _ = import_reference()
     from TransUnet import vit_seg_modeling as vsm
     _case(vsm, loss_mod, sig, meta, GOLD, "transunet_small", ref_transunet.small_config(2), 64, 2, 1, 31, True)
     _case(vsm, loss_mod, sig, meta, GOLD, "transunet_small_rgb4", ref_transunet.small_config(4), 96, 1, 3, 32, True)
+    _case_multitask(vsm, loss_mod, sig, meta, GOLD, "transunet_small_multitask", "VisionTransformerMultitask",
+                    ref_transunet.small_config(2), 64, 2, 1, 35)
+    _case_multitask(vsm, loss_mod, sig, meta, GOLD, "transunet_small_multitask_em", "VisionTransformerMultitaskEM",
+                    ref_transunet.small_config(2), 64, 1, 1, 39)
     if big:
         cfg = ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)
         _case(vsm, loss_mod, sig, meta, GOLD, "transunet_r50_b16_224", cfg, 224, 1, 1, 33, False)

@@ -245,6 +245,9 @@ def _build_decoder(t, tokens, features, dec: DecoderCup, gh, gw):
 
 
 class VisionTransformer(nn.Module):
+    # (decoder attribute, head attribute) per output; the multitask variants below share one encoder between several
+    HEADS = (("decoder", "segmentation_head"),)
+
     def __init__(self, config, img_size=224, num_classes=21843, zero_head=False, vis=False, *, compute_dtype=None):
         super().__init__()
         if vis:
@@ -253,9 +256,11 @@ class VisionTransformer(nn.Module):
         self.zero_head = zero_head
         self.classifier = config.classifier
         self.transformer = Transformer(config, img_size, vis)
-        self.decoder = DecoderCup(config)
-        self.segmentation_head = SegmentationHead(in_channels=config['decoder_channels'][-1],
-                                                  out_channels=config['n_classes'], kernel_size=3)
+        for dname, _ in self.HEADS:                      # reference registration order: all decoders, then all heads
+            setattr(self, dname, DecoderCup(config))
+        for _, hname in self.HEADS:
+            setattr(self, hname, SegmentationHead(in_channels=config['decoder_channels'][-1],
+                                                  out_channels=config['n_classes'], kernel_size=3))
         self.config = config
         self._compute_dtype = compute_dtype
         self._step = 0
@@ -295,10 +300,14 @@ class VisionTransformer(nn.Module):
             for blk in self.transformer.encoder.layer:
                 h = _build_block(tape, h, blk, cfg)
             h = tape.layer_norm(h, self.transformer.encoder.encoder_norm)
-            y = _build_decoder(tape, h, skips, self.decoder, gh, gw)
-            head = self.segmentation_head[0]
-            out_act = tape.conv_bias(y, head.weight, head.bias, out_dtype=torch.float32, pad=head.padding[0])
-            return tape, [a], out_act, tape.output_nchw_plain(out_act)
+            outs = []
+            for dname, hname in self.HEADS:             # every decoder reads the same tokens and skips: their gradients add up
+                y = _build_decoder(tape, h, skips, getattr(self, dname), gh, gw)
+                head = getattr(self, hname)[0]
+                outs.append(tape.conv_bias(y, head.weight, head.bias, out_dtype=torch.float32, pad=head.padding[0]))
+            if len(outs) == 1:
+                return tape, [a], outs[0], tape.output_nchw_plain(outs[0])
+            return tape, [a], tuple(outs), tuple(tape.output_nchw_plain(o) for o in outs)
 
         record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _TapeFunction.apply(run, record, 1, x, *params)
@@ -336,6 +345,17 @@ class VisionTransformer(nn.Module):
             for bname, block in hm.body.named_children():
                 for uname, unit in block.named_children():
                     unit.load_from(weights, n_block=bname, n_unit=uname)
+
+
+class VisionTransformerMultitask(VisionTransformer):
+    """Reference vit_seg_modeling.py:444-522: one Transformer, `decoder1/2` + `segmentation_head1/2`, returns
+    (logits1, logits2).  The encoder runs once per step; both decoders sit on the same tape."""
+    HEADS = (("decoder1", "segmentation_head1"), ("decoder2", "segmentation_head2"))
+
+
+class VisionTransformerMultitaskEM(VisionTransformer):
+    """Reference vit_seg_modeling.py:524-638: six decoders / heads over one encoder, returns six logit maps."""
+    HEADS = tuple((f"decoder{i}", f"segmentation_head{i}") for i in range(1, 7))
 
 
 CONFIGS = {
