@@ -609,3 +609,28 @@ def test_attention_block_odd_shapes_and_input_gradients():
             assert float(p.grad.abs().max()) < 1e-4, k
         else:
             assert rel_err(p.grad, rp.grad) < 1e-3, k
+
+
+def test_trainer_multitask_on_hip_model_follows_reference_run(golden_dir, tmp_path):
+    """Product Trainer.multi_task_train (reference Trainer.py:831-992) driving the HIP `Model.UNet_multitask(1, 1, 8)` (one
+    regression map per head, ReLU + 'mse' in the trainer) against the reference's own run of that loop (fixture)."""
+    _need_gpu()
+    import Model
+    from torch.utils.data import DataLoader
+    from Trainer import Trainer
+    from tools.gen_golden import PairLabels, multitask_trainer_data
+    g = np.load(os.path.join(golden_dir, "trainer_multitask.npz"))
+    m = Model.UNet_multitask(1, 1, 8, False, compute_dtype="fp32")
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=22))
+    m.to(DEV)
+    xs, l1, l2 = multitask_trainer_data()
+    loaders = {"train": DataLoader(PairLabels(xs[:4], l1[:4], l2[:4]), batch_size=2, shuffle=False),
+               "val": DataLoader(PairLabels(xs[4:], l1[4:], l2[4:]), batch_size=1)}
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    tr = Trainer(m, "multi_task", torch.cuda.FloatTensor, DEV, str(tmp_path), loaders, 2, opt, 25, 2, "mse", "mse",
+                 lr_scheduler=True)
+    tr.train()
+    for mine, key in ((tr.train_loss_list, "train_loss"), (tr.val_loss_list, "val_loss"),
+                      (tr.train_loss_list_1, "train_loss_1"), (tr.val_loss_list_2, "val_loss_2")):
+        np.testing.assert_allclose(mine, g[key], rtol=2e-4, atol=2e-5)
+    assert sorted(os.listdir(tmp_path / "models")) == list(g["files"])

@@ -101,3 +101,33 @@ def test_product_init_matches_reference_rng_stream(golden_dir):
     m = Model.UNet(1, 2, 8, False)
     for k, v in m.state_dict().items():
         _sig_close(sig(v.float()), g["init_sig." + k], rtol=1e-6)
+
+
+def test_trainer_multitask_reproduces_reference_run(golden_dir, tmp_path):
+    """Product Trainer.multi_task_train driving the CPU oracle's UNet_multitask == reference Trainer.multi_task_train driving
+    the reference UNet_multitask (Trainer.py:831-992): per-epoch total and per-task losses, poly-LR, checkpoints, final
+    weights.  (The reference itself dies in its plot routine after the last epoch; the product finishes and plots.)"""
+    from Trainer import Trainer
+    from tools.gen_golden import PairLabels, multitask_trainer_data
+    g = np.load(os.path.join(golden_dir, "trainer_multitask.npz"))
+    m = ref_unet.RefUNetMultitask(1, 1, 8, False)
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=22))
+    xs, l1, l2 = multitask_trainer_data()
+    loaders = {"train": DataLoader(PairLabels(xs[:4], l1[:4], l2[:4]), batch_size=2, shuffle=False),
+               "val": DataLoader(PairLabels(xs[4:], l1[4:], l2[4:]), batch_size=1)}
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    tr = Trainer(m, "multi_task", torch.FloatTensor, "cpu", str(tmp_path), loaders, 2, opt, 25, 2, "mse", "mse",
+                 lr_scheduler=True)
+    assert tr.train() is m
+    for mine, key in ((tr.train_loss_list, "train_loss"), (tr.val_loss_list, "val_loss"),
+                      (tr.train_loss_list_1, "train_loss_1"), (tr.train_loss_list_2, "train_loss_2"),
+                      (tr.val_loss_list_1, "val_loss_1"), (tr.val_loss_list_2, "val_loss_2")):
+        np.testing.assert_allclose(mine, g[key], rtol=0, atol=5e-6)
+    assert tr.iter_num == int(g["iter_num"]) and abs(opt.param_groups[0]["lr"] - float(g["final_lr"])) < 1e-12
+    assert abs(tr.best_val_score - float(g["best_val_score"])) < 5e-6          # model selection on the validation loss
+    assert sorted(os.listdir(tmp_path / "models")) == list(g["files"])
+    assert (tmp_path / "total.png").exists()
+    for k, v in m.state_dict().items():
+        _sig_close(sig(v.float()), g["final." + k], rtol=5e-4)
+    with pytest.raises(NotImplementedError):
+        Trainer(m, "multi_task", torch.FloatTensor, "cpu", str(tmp_path), loaders, 2, opt, 25, 2, "multi_task_loss", "mse").train()

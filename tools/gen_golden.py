@@ -286,6 +286,64 @@ def gen_trainer(Model, loss_mod, Trainer):
     print("wrote trainer_single.npz", out["train_loss"], out["val_loss"], files)
 
 
+class PairLabels(torch.utils.data.Dataset):
+    """(x, (label1, label2)) items: the batch format reference Trainer.multi_task_train unpacks (Trainer.py:865-866)."""
+
+    def __init__(self, x, l1, l2):
+        self.x, self.l1, self.l2 = x, l1, l2
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, i):
+        return self.x[i], (self.l1[i], self.l2[i])
+
+
+def multitask_trainer_data(seed=22):
+    """Two regression-style target maps per image (the multi-task loop clamps the outputs with ReLU, Trainer.py:883-884)."""
+    xs, l1 = recipe.synthetic_batch(6, 1, 32, 32, 2, seed=seed)
+    _, l2 = recipe.synthetic_batch(6, 1, 32, 32, 3, seed=seed + 100)
+    return xs, l1, 0.5 * l2
+
+
+def gen_trainer_multitask(Model, loss_mod, Trainer):
+    """Reference Trainer.multi_task_train (Trainer.py:831-992) on reference UNet_multitask(1, 1, 8), 'mse' loss, CPU."""
+    from torch.utils.data import DataLoader
+    torch.manual_seed(0)
+    m = Model.UNet_multitask(1, 1, 8, False)
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=22))
+    xs, l1, l2 = multitask_trainer_data()
+    loaders = {"train": DataLoader(PairLabels(xs[:4], l1[:4], l2[:4]), batch_size=2, shuffle=False),
+               "val": DataLoader(PairLabels(xs[4:], l1[4:], l2[4:]), batch_size=1)}
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    with tempfile.TemporaryDirectory() as d:
+        cwd = os.getcwd()
+        os.chdir(d)
+        tr = Trainer.Trainer(m, "multi_task", torch.FloatTensor, "cpu", d, loaders, 2, opt, 25, 2, "mse", "mse",
+                             lr_scheduler=True)
+        crashed = False
+        try:
+            tr.train()
+        except ValueError as e:
+            # the reference's loop finishes training and then dies in plot_loss_functions (Trainer.py:69: val_score_list is
+            # never filled by multi_task_train, so matplotlib gets x and y of different lengths); everything recorded below
+            # was produced before that point
+            crashed = "same first dimension" in str(e)
+            if not crashed:
+                raise
+        os.chdir(cwd)
+        files = sorted(os.listdir(os.path.join(d, "models")))
+    out = dict(train_loss=np.array(tr.train_loss_list), val_loss=np.array(tr.val_loss_list),
+               train_loss_1=np.array(tr.train_loss_list_1), train_loss_2=np.array(tr.train_loss_list_2),
+               val_loss_1=np.array(tr.val_loss_list_1), val_loss_2=np.array(tr.val_loss_list_2),
+               iter_num=tr.iter_num, final_lr=opt.param_groups[0]["lr"], files=np.array(files),
+               best_val_score=float(tr.best_val_score), reference_crashed_in_plot=crashed)
+    for k, v in m.state_dict().items():                         # weights after the last step (best-model reload never ran)
+        out["final." + k] = sig(v.float())
+    np.savez_compressed(os.path.join(GOLD, "trainer_multitask.npz"), **out, **meta())
+    print("wrote trainer_multitask.npz", out["train_loss"], out["val_loss"], files)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -307,6 +365,8 @@ def main():
         gen_unet_attention(Model, loss_mod)
     if a.only in (None, "trainer"):
         gen_trainer(Model, loss_mod, Trainer)
+    if a.only in (None, "trainer_multitask"):
+        gen_trainer_multitask(Model, loss_mod, Trainer)
     if a.only in (None, "transunet"):
         try:
             from tools import gen_golden_transunet

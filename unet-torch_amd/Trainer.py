@@ -10,8 +10,12 @@ files `logs.txt`, `models/{epochN,best,last_epoch}.pt`, `total.png`.
 
 Differences, all host-side: the step body is factored into `train_step` (reused by the
 data-parallel runner, umi/ddp.py) and the running loss is accumulated on the device and read
-back once per epoch instead of a `.item()` sync every step (Trainer.py:727).  The other epoch
-loops of the reference (multi-task, CLTR, Topo losses) are out of scope and raise.
+back once per epoch instead of a `.item()` sync every step (Trainer.py:727).
+`multi_task_train` (Trainer.py:831-992; model types 'multi_task*' with a plain loss name): two-headed models
+(`Model.UNet_multitask`, `VisionTransformerMultitask`), batches `(inputs, (label1, label2))`, both outputs through
+`F.relu` (:883-884), loss = loss1 + loss2 (:885-890), model selection on the validation LOSS (:926).
+The remaining epoch loops of the reference (uncertainty / ratio weighted multi-task, CLTR, Topo losses) are out of scope
+and raise.
 """
 import copy
 import os
@@ -26,7 +30,8 @@ from loss import calc_loss
 _SINGLE = ('single', 'TransUnet', 'regression', 'regression_t', 'attention')
 _TOPO = ('TopoCount', 'TopoCount2', 'TopoLoss', 'TopoLoss2', 'MyTopoLoss1', 'MyTopoLoss2', 'MyTopoLossGraph',
          'MyTopoLossVR')
-_OTHER = ('multi_task', 'multi_task_reg', 'multi_task_regTU', 'CLTR')
+_MULTI = ('multi_task', 'multi_task_reg', 'multi_task_regTU')
+_OTHER = ('CLTR',)
 
 
 class Trainer():
@@ -56,6 +61,7 @@ class Trainer():
         self.best_model = []
         self.early_stop_counter = 0
         self.train_loss_list, self.val_loss_list, self.val_score_list = [], [], []
+        self.train_loss_list_1, self.train_loss_list_2, self.val_loss_list_1, self.val_loss_list_2 = [], [], [], []
         self.grad_sync = None         # optional callable run between backward and optimizer.step (DDP)
 
         self.save_dir_model = os.path.join(self.output_save_dir, 'models/')
@@ -67,15 +73,26 @@ class Trainer():
             if self.loss_function in _TOPO:
                 raise NotImplementedError("Topo-loss warm-up loop (reference singe_train_wup) is out of scope")
             return self.singe_train()
+        if self.model_type in _MULTI:
+            if self.loss_function in ('multi_task_loss', 'multi_task_loss_ratio'):
+                raise NotImplementedError("uncertainty- / ratio-weighted multi-task loops (reference multi_task_uc_train, "
+                                          "multi_task_trainRatio) are out of scope")
+            return self.multi_task_train()
         if self.model_type in _OTHER:
-            raise NotImplementedError(f'model_type "{self.model_type}" (multi-task / CLTR loops) is out of scope')
+            raise NotImplementedError(f'model_type "{self.model_type}" (CLTR loop) is out of scope')
         raise ValueError('Invalid model_type "%s"' % self.model_type)
 
     # ------------------------------------------------------------------------------------
     def _to_device(self, inputs, labels):
+        if isinstance(labels, (list, tuple)):                    # multi-task batches: labels = (label1, label2)
+            return inputs.to(self.device).type(self.dtype), tuple(l.to(self.device).type(self.dtype) for l in labels)
         return inputs.to(self.device).type(self.dtype), labels.to(self.device).type(self.dtype)
 
     def _forward_loss(self, inputs, labels):
+        if self.model_type in _MULTI:                            # reference Trainer.py:882-890
+            outs = tuple(F.relu(o) for o in self.model(inputs))
+            self._task_losses = [calc_loss(o, l, loss_type=self.loss_function) for o, l in zip(outs, labels)]
+            return outs, self._task_losses[0] + self._task_losses[1]
         out = self.model(inputs)
         if self.model_type in ('regression', 'regression_t'):
             out = F.relu(out)
@@ -102,11 +119,17 @@ class Trainer():
         inputs, labels = self._to_device(inputs, labels)
         with torch.no_grad():
             out, loss = self._forward_loss(inputs, labels)
+            if self.model_type in _MULTI:                        # the reference reports no validation score there (:853)
+                return loss.detach(), torch.zeros((), device=loss.device)
             score = calc_loss(out, labels, loss_type=self.accuracy_metric)
         return loss.detach(), score.detach()
 
     # ------------------------------------------------------------------------------------
+    def multi_task_train(self):
+        return self.singe_train()                                # same epoch loop; the differences are flagged `multi` below
+
     def singe_train(self):
+        multi = self.model_type in _MULTI
         os.makedirs(self.output_save_dir, exist_ok=True)
         log = open(os.path.join(self.output_save_dir, "logs.txt"), 'a')
 
@@ -131,6 +154,7 @@ class Trainer():
                 self.model.train(train)
 
                 loss_sum, score_sum, steps = None, None, 0
+                task_sums = [0.0, 0.0]
                 with tqdm(self.dataloader[phase], unit="batch") as bar:
                     for inputs, labels in bar:
                         bar.set_description(f"Epoch {epoch}")
@@ -141,6 +165,8 @@ class Trainer():
                             loss, score = self.eval_step(inputs, labels)
                             score_sum = score if score_sum is None else score_sum + score
                         loss_sum = loss if loss_sum is None else loss_sum + loss
+                        if multi:
+                            task_sums = [s_ + l_.detach() for s_, l_ in zip(task_sums, self._task_losses)]
                         if steps % 50 == 0 or not use_cuda:     # avoid a device sync on every step
                             mem = f'{torch.cuda.memory_reserved() / 1E9 if use_cuda else 0:.3g}G/' + total_mem
                             bar.set_postfix(loss=float(loss_sum) / steps, memory=mem)
@@ -150,6 +176,9 @@ class Trainer():
                     elapsed = time.time() - since
                     say('Training Time for this epoch: {:.0f}m {:.0f}s\n'.format(elapsed // 60, elapsed % 60))
                     self.train_loss_list.append(epoch_loss)
+                    if multi:
+                        self.train_loss_list_1.append(float(task_sums[0]) / steps)
+                        self.train_loss_list_2.append(float(task_sums[1]) / steps)
                     say("Train loss on epoch %i: %f" % (epoch, epoch_loss))
                     total_time += elapsed
                     self.meanTimePerEpoch = total_time / epoch
@@ -159,13 +188,17 @@ class Trainer():
                     continue
 
                 val_score = float(score_sum) / steps
+                if multi:
+                    self.val_loss_list_1.append(float(task_sums[0]) / steps)
+                    self.val_loss_list_2.append(float(task_sums[1]) / steps)
                 self.val_loss_list.append(epoch_loss)
                 self.val_score_list.append(val_score)
                 say("Val loss on epoch %i: %f" % (epoch, epoch_loss))
                 say("Val score on epoch %i: %f" % (epoch, val_score))
-                if val_score < self.best_val_score:
+                selector = epoch_loss if multi else val_score   # multi-task: best model by validation loss (:926)
+                if selector < self.best_val_score:
                     self.early_stop_counter = 0
-                    self.best_val_score = val_score
+                    self.best_val_score = selector
                     self.best_loss = epoch_loss
                     say("saving best model")
                     self.best_model = copy.deepcopy(self.model.state_dict())
