@@ -634,3 +634,39 @@ def test_trainer_multitask_on_hip_model_follows_reference_run(golden_dir, tmp_pa
                       (tr.train_loss_list_1, "train_loss_1"), (tr.val_loss_list_2, "val_loss_2")):
         np.testing.assert_allclose(mine, g[key], rtol=2e-4, atol=2e-5)
     assert sorted(os.listdir(tmp_path / "models")) == list(g["files"])
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 70, 90), (3, 3, 33, 47), (2, 1, 16, 16)])
+def test_unet_ragged_sizes_match_oracle(shape):
+    """Spatial sizes that are not multiples of 16 (every level floors in the encoder and pads in the decoder, reference
+    Model.py:69-73), batch 1 and 3, and the smallest map the 4-level network accepts (1x1 at the bottom; batch 2 because
+    BatchNorm refuses a single value per channel in training mode, in the reference too): fp32 logits and all gradients vs
+    the oracle."""
+    _need_gpu()
+    import Model
+    import loss as L
+    B, cin, H, W = shape
+    ncls = 3
+    L.CLASS_NUMBER = ncls
+    ref = ref_unet.RefUNet(cin, ncls, 8, False)
+    ref.load_state_dict(recipe.fill_state_dict(ref.state_dict(), seed=40 + H))
+    x, lab = recipe.synthetic_batch(B, cin, H, W, ncls, seed=40 + H)
+    m = Model.UNet(cin, ncls, 8, False, compute_dtype="fp32")
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).train()
+    ref.train()
+    logits = m(x.to(DEV))
+    rl = ref(x)
+    assert tuple(logits.shape) == (B, ncls, H, W)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), rl.detach().numpy(), rtol=1e-4,
+                               atol=1e-4 * float(rl.detach().abs().max()))
+    L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc").backward()
+    ref_unet.dice_bce_mc(rl, lab, ncls).backward()
+    errs = {k: rel_err(p.grad, rp.grad) for (k, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters())}
+    # (a ReLU input within rounding of zero can flip between two fp32 implementations, see DESIGN.md section 8; the bound
+    #  leaves room for one such element in these small maps, a wrong pad / crop offset would be O(1))
+    # (the 16x16 case has 1x1 .. 8x8 maps below the first level: a single flipped mask is a large share of such a tensor,
+    #  and BatchNorm over 2 values per channel amplifies rounding by up to 1/sqrt(eps); measured 6e-2 there)
+    tiny = H * W <= 256
+    assert max(errs.values()) < (1e-1 if tiny else 3e-2), max(errs.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(errs.values()))) < (6e-2 if tiny else 2e-3)
