@@ -16,7 +16,11 @@ lab = torch.randint(0, 2, (2, 64, 64), device=DEV).float()
 
 
 def make(model):
-    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    # the fused optimizer (one launch per step; its descriptor table is uploaded from pinned memory, also under capture)
+    # unless "torch" is passed on the command line
+    from umi import optim as umi_optim
+    cls = torch.optim.SGD if "torch" in sys.argv[1:] else umi_optim.SGD
+    opt = cls(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
 
     def step(xx, yy):
         loss = L.calc_loss(model(xx), yy, loss_type="dice_bce_mc")

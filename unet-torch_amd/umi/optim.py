@@ -24,10 +24,26 @@ def _bump(p):
 
 
 class _Table:
-    """Device descriptor table of one param group, rebuilt only when a pointer changes."""
+    """Device descriptor table of one param group, rebuilt only when a pointer changes.
+
+    The upload is stream-capture safe: the pinned staging buffers and the device buffer are allocated once (outside any
+    capture: `umi.graphs.GraphedStep` warms up first) and reused, so a rebuild during HIP-graph capture is a plain
+    pinned -> device async copy (a legal graph node).  That node re-reads the pinned buffer at every replay, so an optimizer
+    that was captured into a graph must not also be stepped eagerly afterwards (GraphedStep owns it)."""
 
     def __init__(self):
-        self.key, self.dev, self.host, self.blocks, self.n = None, None, None, 0, 0
+        self.key, self.dev, self.blocks, self.n = None, None, 0, 0
+        self.host, self.events, self.turn = [None, None], [None, None], 0
+
+    def _ensure(self, nbytes):
+        if self.dev is None or self.dev.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("umi.optim: first optimizer step inside a HIP-graph capture; run a warm-up step first "
+                                   "(umi.graphs.GraphedStep does)")
+            cap = max(nbytes, 16384)
+            self.dev = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            self.host = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.events = [None, None]
 
     def get(self, rows):
         key = tuple(rows)
@@ -38,7 +54,18 @@ class _Table:
             for i, (p, g, s0, s1, n) in enumerate(rows):
                 arr[i] = (p, g, s0, s1, n, b0, 0)
                 b0 += (n + blk - 1) // blk
-            self.dev, self.host = ops.upload_table(arr)
+            raw = arr.view(np.uint8).reshape(-1)
+            self._ensure(raw.size)
+            capturing = torch.cuda.is_current_stream_capturing()
+            self.turn ^= 1                               # two staging buffers: the previous upload may still be in flight
+            ev = self.events[self.turn]
+            if ev is not None and not capturing:
+                ev.synchronize()
+            self.host[self.turn].numpy()[:raw.size] = raw
+            self.dev[:raw.size].copy_(self.host[self.turn][:raw.size], non_blocking=True)
+            if not capturing:
+                self.events[self.turn] = torch.cuda.Event()
+                self.events[self.turn].record()
             self.key, self.blocks, self.n = key, b0, len(rows)
         return self.dev.data_ptr(), self.n, self.blocks
 
