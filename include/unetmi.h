@@ -223,6 +223,9 @@ typedef struct umi_optim_desc {
     int pad_;
 } umi_optim_desc;
 int umi_optim_block_elems(void);
+/* Copies a descriptor table from PINNED (device-mapped) host memory to device memory with a kernel, so that the upload is a
+ * plain kernel node inside a HIP-graph capture; nbytes and both pointers are multiples of 16. */
+int umi_table_upload(const void* host_pinned, void* dev, size_t nbytes, umi_stream_t stream);
 /* hyper-parameters are doubles (Python floats) and are rounded to fp32 where torch rounds them */
 int umi_optim_sgd_multi(const void* descs, int n_desc, int total_blocks, double lr, double momentum, double dampening,
                         double weight_decay, int nesterov, int first_step, umi_stream_t stream);

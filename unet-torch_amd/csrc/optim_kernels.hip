@@ -9,6 +9,7 @@
 // are (a U-Net has 3x3x1024x1024 weights next to 64-element BatchNorm vectors).  HBM-bound streaming work: 16-byte
 // accesses whenever the four pointers of a tensor allow it.
 #include "common.h"
+#include <stdint.h>
 
 namespace {
 
@@ -152,6 +153,23 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restr
 }
 
 }  // namespace
+
+// Descriptor-table upload as a KERNEL: `src` is pinned host memory (device-mapped), `dst` the device copy the update /
+// pack kernels read.  Inside a HIP-graph capture this is an ordinary kernel node that re-reads the host buffer on every
+// replay; a captured host-to-device memcpy of a torch pinned buffer did not replay reliably on ROCm 7.2 (the replayed
+// optimizer step saw a stale table).
+__global__ __launch_bounds__(256) void table_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int umi_table_upload(const void* host_pinned, void* dev, size_t nbytes, umi_stream_t stream) {
+    if (!host_pinned || !dev || nbytes == 0 || (nbytes & 15) || (((uintptr_t)host_pinned | (uintptr_t)dev) & 15)) return UMI_ERR_BADARG;
+    const int n16 = (int)(nbytes / 16);
+    int grid = (n16 + 255) / 256;
+    if (grid > 64) grid = 64;
+    hipLaunchKernelGGL(table_upload_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)host_pinned, (uint4*)dev, n16);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
 
 extern "C" int umi_optim_block_elems(void) { return OPT_BLOCK; }
 extern "C" int umi_pack_block_elems(void) { return PACK_BLOCK; }

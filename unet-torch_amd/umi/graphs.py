@@ -25,6 +25,12 @@ class GraphedStep:
         if not all(t.is_cuda for t in example_inputs):
             raise RuntimeError("GraphedStep needs device-resident example inputs")
         self.static_inputs = [t.clone() for t in example_inputs]
+        # The graph refers to everything the step touched by ADDRESS: parameters, optimizer state (momentum buffers, the fused
+        # optimizer's descriptor tables in pinned host memory), weight-pack caches.  Keep the closure -- and through it the
+        # model and the optimizer -- alive as long as the graph: an optimizer that only the closure referenced would be
+        # collected after __init__, its buffers handed to the next allocation, and the replayed update would read them
+        # (observed: the graphed model stops learning, or a memory fault).
+        self._step_fn = step_fn
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -95,6 +95,7 @@ SIGNATURES = {
     "umi_dice_ce_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umi_dice_ce_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
     "umi_optim_block_elems": (c_int, []),
+    "umi_table_upload": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "umi_optim_sgd_multi": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_int, c_void_p]),
     "umi_optim_adam_multi": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_double,
                                      c_void_p]),

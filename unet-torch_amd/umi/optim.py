@@ -27,9 +27,10 @@ class _Table:
     """Device descriptor table of one param group, rebuilt only when a pointer changes.
 
     The upload is stream-capture safe: the pinned staging buffers and the device buffer are allocated once (outside any
-    capture: `umi.graphs.GraphedStep` warms up first) and reused, so a rebuild during HIP-graph capture is a plain
-    pinned -> device async copy (a legal graph node).  That node re-reads the pinned buffer at every replay, so an optimizer
-    that was captured into a graph must not also be stepped eagerly afterwards (GraphedStep owns it)."""
+    capture: `umi.graphs.GraphedStep` warms up first) and reused, and the copy is a kernel (`umi_table_upload`) reading the
+    device-mapped pinned buffer, i.e. an ordinary kernel node of the graph.  That node re-reads the pinned buffer at every
+    replay, so an optimizer that was captured into a graph must not also be stepped eagerly afterwards (GraphedStep owns
+    it)."""
 
     def __init__(self):
         self.key, self.dev, self.blocks, self.n = None, None, 0, 0
@@ -54,7 +55,7 @@ class _Table:
             for i, (p, g, s0, s1, n) in enumerate(rows):
                 arr[i] = (p, g, s0, s1, n, b0, 0)
                 b0 += (n + blk - 1) // blk
-            raw = arr.view(np.uint8).reshape(-1)
+            raw = arr.view(np.uint8).reshape(-1)                 # 48 B per row: a multiple of 16
             self._ensure(raw.size)
             capturing = torch.cuda.is_current_stream_capturing()
             self.turn ^= 1                               # two staging buffers: the previous upload may still be in flight
@@ -62,7 +63,8 @@ class _Table:
             if ev is not None and not capturing:
                 ev.synchronize()
             self.host[self.turn].numpy()[:raw.size] = raw
-            self.dev[:raw.size].copy_(self.host[self.turn][:raw.size], non_blocking=True)
+            L.check(L.fn("umi_table_upload")(self.host[self.turn].data_ptr(), self.dev.data_ptr(), raw.size, ops._stream()),
+                    "umi_table_upload")
             if not capturing:
                 self.events[self.turn] = torch.cuda.Event()
                 self.events[self.turn].record()
