@@ -162,8 +162,9 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step from a captured HIP graph (umi.graphs.GraphedStep; single GPU only, opt-in)")
+    ap.add_argument("--graph", action="store_true", help="(default on one GPU) replay the step from a captured HIP graph")
+    ap.add_argument("--eager", action="store_true",
+                    help="issue every step's ~350 launches from Python instead of replaying a captured HIP graph of the step")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,8 +214,12 @@ def main():
         opt.step()
         return loss
 
+    # One GPU: the step (forward + loss + backward + optimizer) is captured once into a HIP graph and replayed, so the
+    # measurement does not depend on how fast the host issues the launches (same kernels, same order; the replayed
+    # trajectory is bit-identical to the eager one, tests/test_gpu_unet.py).  The W warm-up steps run eagerly before the
+    # capture, which itself executes nothing.  Data parallel: eager (the RCCL all-reduce is not captured).
     graphed = None
-    if a.graph and world == 1:
+    if world == 1 and not a.eager and os.environ.get("UMI_BENCH_GRAPH", "1") != "0":
         from umi.graphs import GraphedStep
 
         def step_xy(xx, yy):
@@ -224,9 +229,14 @@ def main():
             loss.backward()
             opt.step()
             return loss
-        graphed = GraphedStep(step_xy, [x, labels], warmup=max(1, a.warmup))     # warm-up steps run eagerly on a side stream
-        step = lambda: graphed(x, labels)                                        # noqa: E731
-    else:
+        try:
+            graphed = GraphedStep(step_xy, [x, labels], warmup=max(1, a.warmup))   # warm-up steps run eagerly on a side stream
+            step = lambda: graphed(x, labels)                                      # noqa: E731
+        except Exception as e:                                                     # capture refused: measure the eager path
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            graphed = None
+            torch.cuda.synchronize()
+    if graphed is None:
         for _ in range(a.warmup):
             step()
 

@@ -115,6 +115,14 @@ int umi_bn_bwd_apply(void* da, int ldda, const void* y, int ldy, const void* tx,
 int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, void* da, int ldda, const void* ybn, int ldybn,
                          const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
                          int dtype, umi_stream_t stream);
+/* The same fusion on the other producer of such a gradient: MaxPool2d(2) backward (reference Model.py:36) routes `dpool` into
+ * `da` (accumulate != 0: adds to the skip-connection gradient already there) and, being the LAST contribution to `da`, also
+ * emits stage 1 of the BatchNorm backward of the pooled layer (x = its raw output, tx / rstd its transform and 1/std):
+ * part[rows][2][C], rows = umi_pool2_bwd_bnred_stat_rows().  fp16, even H and W, C % 8 == 0; else UMI_ERR_UNSUPPORTED
+ * (caller uses umi_pool2_bwd + umi_bn_bwd_reduce). */
+int umi_pool2_bwd_bnred_stat_rows(int N, int H, int W, int C);
+int umi_pool2_bwd_bnred(const void* dpool, int lddp, const void* x, int ldx, const void* tx, const float* rstd, void* da,
+                        int ldda, int accumulate, float* part, int N, int H, int W, int C, int dtype, umi_stream_t stream);
 int umi_bn_bwd_from_partials(const float* part, int rows, int C, float* sum_dz, float* sum_dzx, umi_stream_t stream);
 
 /* Weight gradient of umi_conv_fwd (autograd of the reference convs):

@@ -453,3 +453,35 @@ def test_argmax_mask_matches_softmax_argmax(N, C, H, W):
     assert torch.equal(got[safe], want[safe])
     assert int(got[0, 0, 0]) == 0
     assert torch.equal(got, torch.argmax(logits, dim=1).to(torch.uint8))
+
+
+@pytest.mark.parametrize("shape,acc", [((2, 16, 24, 64), True), ((1, 8, 8, 8), False), ((3, 32, 16, 128), True)])
+def test_pool2_bwd_with_bn_reduction_matches_separate_kernels(shape, acc):
+    """umi_pool2_bwd_bnred (max-pool backward + stage 1 of the pooled layer's BatchNorm backward) against umi_pool2_bwd
+    followed by umi_bn_bwd_reduce on the same inputs: identical routed gradient, sums equal up to fp32 summation order."""
+    lib, ops = _gpu()
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, H, W, C, generator=g).half().to(DEV)
+    t = _tx(C, g)
+    t[:, 0] = 0.1 * torch.randn(C, generator=g)
+    td = t.to(DEV).contiguous()
+    rstd = (0.5 + torch.rand(C, generator=g)).to(DEV)
+    dp = (torch.randn(N, H // 2, W // 2, C, generator=g) * 0.1).half().to(DEV)
+    da0 = (torch.randn(N, H, W, C, generator=g) * 0.1).half().to(DEV)
+    da_a, da_b = da0.clone(), da0.clone()
+    ops.pool2_bwd(dp, x, td, da_a, acc)
+    part = ops.pool2_bwd_bnred(dp, x, td, rstd, da_b, acc)
+    assert part is not None
+    assert torch.equal(da_a, da_b)
+    sums = torch.empty(2, C, dtype=torch.float32, device=DEV)
+    lib.check(lib.fn("umi_bn_bwd_from_partials")(part.data_ptr(), part.numel() // (2 * C), C, sums[0].data_ptr(),
+                                                 sums[1].data_ptr(), ops._stream()), "from_partials")
+    ref = torch.empty(2, C, dtype=torch.float32, device=DEV)
+    M = N * H * W
+    nb = lib.fn("umi_bn_bwd_ws_bytes")(M, C)
+    ws = ops.workspace(nb, x.device)
+    lib.check(lib.fn("umi_bn_bwd_reduce")(da_a.data_ptr(), C, x.data_ptr(), C, td.data_ptr(), rstd.data_ptr(), ref[0].data_ptr(),
+                                          ref[1].data_ptr(), M, C, lib.UMI_F16, ws.data_ptr(), ws.numel(), ops._stream()),
+              "reduce")
+    torch.testing.assert_close(sums.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))

@@ -130,6 +130,24 @@ extern "C" int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, v
 }
 
 // stage 2 of the BatchNorm backward reduction on partial rows produced by umi_conv_dgrad_bnred
+int umi_pool2_bwd_bnred_rows(int N, int H, int W, int C);
+bool umi_pool2_bwd_bnred_f16v(const void* dp, int lddp, const void* x, int ldx, const void* tx, const float* rstd, void* da,
+                              int ldda, int accumulate, float* part, int N, int H, int W, int C, hipStream_t s);
+
+// MaxPool2d(2) backward into `da` + stage 1 of the BatchNorm backward of the pooled layer (x = its raw output): only when
+// this is the last contribution to `da`.  *rows receives the partial rows written (part[rows][2][C]).
+extern "C" int umi_pool2_bwd_bnred(const void* dpool, int lddp, const void* x, int ldx, const void* tx, const float* rstd,
+                                   void* da, int ldda, int accumulate, float* part, int N, int H, int W, int C, int dtype,
+                                   umi_stream_t stream) {
+    if (!dpool || !x || !tx || !rstd || !da || !part || N <= 0 || H <= 0 || W <= 0 || C <= 0) return UMI_ERR_BADARG;
+    if (dtype != UMI_F16) return UMI_ERR_UNSUPPORTED;
+    if (!umi_pool2_bwd_bnred_f16v(dpool, lddp, x, ldx, tx, rstd, da, ldda, accumulate, part, N, H, W, C, (hipStream_t)stream))
+        return UMI_ERR_UNSUPPORTED;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+extern "C" int umi_pool2_bwd_bnred_stat_rows(int N, int H, int W, int C) { return umi_pool2_bwd_bnred_rows(N, H, W, C); }
+
 extern "C" int umi_bn_bwd_from_partials(const float* part, int rows, int C, float* sum_dz, float* sum_dzx, umi_stream_t stream) {
     if (!part || !sum_dz || !sum_dzx || rows <= 0 || C <= 0) return UMI_ERR_BADARG;
     umi_launch_reduce_rows2(part, rows, C, sum_dz, sum_dzx, 1.f, (hipStream_t)stream);

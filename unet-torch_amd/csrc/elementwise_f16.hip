@@ -195,10 +195,18 @@ __global__ __launch_bounds__(256) void pool2_fwd_v8(const half_t* __restrict__ x
 }
 
 // ---- MaxPool2d(2) backward: first arg-max of tx(x) gets dpool (even H and W only) -----------------------------
-template <bool HAS_TX, bool ACC>
+// RED: the pooled tensor is the output of a BatchNorm+ReLU layer (tx, rstd) and this is the LAST contribution to its
+// gradient: the kernel then also emits stage 1 of that layer's BatchNorm backward reduction (per-workgroup sums of dz and
+// dz*xhat over the values it stores, ws[block][2][C]) -- the separate reduction pass over da and x disappears.
+template <bool HAS_TX, bool ACC, bool RED = false>
 __global__ __launch_bounds__(256) void pool2_bwd_v8(const half_t* __restrict__ dp, int lddp, const half_t* __restrict__ x,
                                                     int ldx, const float4* __restrict__ tx, half_t* __restrict__ da,
-                                                    int ldda, int N, int H, int W, int C) {
+                                                    int ldda, int N, int H, int W, int C,
+                                                    const float* __restrict__ rstd = nullptr, float* __restrict__ ws = nullptr) {
+    __shared__ float red[RED ? 2 : 1][RED ? 256 : 1][9];
+    float rs[8], s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rs[j] = s[j] = q[j] = 0.f;
     const int G = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long gt = (long)blockIdx.x * 256 + threadIdx.x;
     const int cg = (int)(gt % G);
@@ -208,6 +216,10 @@ __global__ __launch_bounds__(256) void pool2_bwd_v8(const half_t* __restrict__ d
     if (HAS_TX) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) t[j] = tx[cg * 8 + j];
+    }
+    if (RED) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rs[j] = rstd[cg * 8 + j];
     }
     for (long p = gt / G; p < P; p += stride_p) {
         int wo = (int)(p % Wo);
@@ -239,10 +251,28 @@ __global__ __launch_bounds__(256) void pool2_bwd_v8(const half_t* __restrict__ d
             for (int d = 0; d < 4; ++d) {
                 float add = (d == best) ? (float)g[j] : 0.f;
                 o[d][j] = ACC ? (half_t)((float)o[d][j] + add) : (half_t)add;
+                if (RED) {                      // sums over the STORED (fp16) gradient, like the apply pass will read it
+                    const float yy = (float)v[d][j];
+                    const float dz = umi_tx_pre(yy, t[j]) > t[j].w ? (float)o[d][j] : 0.f;
+                    s[j] += dz;
+                    q[j] = fmaf(dz, (yy - t[j].x) * rs[j], q[j]);
+                }
             }
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d) *reinterpret_cast<half8*>(da + (pix + off[d]) * ldda + cg * 8) = o[d];
+    }
+    if (RED) {
+        const int tid = threadIdx.x, PL = 256 / G;         // 256 % G == 0: this thread's group is tid % G (as gt % G)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[0][tid][j] = s[j]; red[1][tid][j] = q[j]; }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += 256) {
+            const int which = i / C, c = i - which * C;
+            float a = 0.f;
+            for (int k = 0; k < PL; ++k) a += red[which][k * G + (c >> 3)][c & 7];
+            ws[((long)blockIdx.x * 2 + which) * C + c] = a;
+        }
     }
 }
 
@@ -309,12 +339,31 @@ bool umi_pool2_fwd_f16v(const void* x, int ldx, const void* tx, void* y, int ldy
     return true;
 }
 
+// pool backward + BatchNorm-backward stage 1 of the pooled layer: rows of partial sums written, or 0 when it does not apply
+int umi_pool2_bwd_bnred_rows(int N, int H, int W, int C) {
+    if (((H | W) & 1) || C % 8 || C / 8 > 256 || 256 % (C / 8)) return 0;
+    return grid_for((long)N * (H / 2) * (W / 2) * (C / 8));
+}
+bool umi_pool2_bwd_bnred_f16v(const void* dp, int lddp, const void* x, int ldx, const void* tx, const float* rstd, void* da,
+                              int ldda, int accumulate, float* part, int N, int H, int W, int C, hipStream_t s) {
+    if (!tx || !rstd || !part || !umi_pool2_bwd_bnred_rows(N, H, W, C)) return false;
+    if (!vec_ok(C, ldx, ldda, x, da) || lddp % 8 || !al16(dp)) return false;
+    const int grid = umi_pool2_bwd_bnred_rows(N, H, W, C);
+    if (accumulate)
+        hipLaunchKernelGGL((pool2_bwd_v8<true, true, true>), dim3(grid), dim3(256), 0, s, (const half_t*)dp, lddp, (const half_t*)x,
+                           ldx, (const float4*)tx, (half_t*)da, ldda, N, H, W, C, rstd, part);
+    else
+        hipLaunchKernelGGL((pool2_bwd_v8<true, false, true>), dim3(grid), dim3(256), 0, s, (const half_t*)dp, lddp, (const half_t*)x,
+                           ldx, (const float4*)tx, (half_t*)da, ldda, N, H, W, C, rstd, part);
+    return true;
+}
+
 bool umi_pool2_bwd_f16v(const void* dp, int lddp, const void* x, int ldx, const void* tx, void* da, int ldda,
                         int accumulate, int N, int H, int W, int C, hipStream_t s) {
     if ((H | W) & 1) return false;                        // odd tails stay on the generic kernel
     if (!vec_ok(C, ldx, ldda, x, da) || lddp % 8 || !al16(dp)) return false;
     int grid = grid_for((long)N * (H / 2) * (W / 2) * (C / 8));
-#define GO(T, A) hipLaunchKernelGGL((pool2_bwd_v8<T, A>), dim3(grid), dim3(256), 0, s, (const half_t*)dp, lddp, (const half_t*)x, ldx, (const float4*)tx, (half_t*)da, ldda, N, H, W, C)
+#define GO(T, A) hipLaunchKernelGGL((pool2_bwd_v8<T, A>), dim3(grid), dim3(256), 0, s, (const half_t*)dp, lddp, (const half_t*)x, ldx, (const float4*)tx, (half_t*)da, ldda, N, H, W, C, (const float*)nullptr, (float*)nullptr)
     if (tx) { if (accumulate) GO(true, true); else GO(true, false); }
     else    { if (accumulate) GO(false, true); else GO(false, false); }
 #undef GO

@@ -28,13 +28,16 @@ def _fuse_bnred():
 class Act:
     """Lazily-activated NHWC tensor.  `raw` is an [N,H,W,C] view, `tx` the consumer transform
     (None = consume as stored).  `grad` = d loss / d activated value (same layout/dtype)."""
-    __slots__ = ("raw", "tx", "grad", "parts", "needs_grad", "bn_rstd", "bn_part")
+    __slots__ = ("raw", "tx", "grad", "parts", "needs_grad", "bn_rstd", "bn_part", "bn_part_at", "gives")
 
     def __init__(self, raw, tx=None, parts=None, needs_grad=True):
         self.raw, self.tx, self.grad, self.parts, self.needs_grad = raw, tx, None, parts, needs_grad
         self.bn_rstd = None       # conv_bn outputs: 1/std of the batch statistics (BatchNorm backward)
-        self.bn_part = None       # stage-1 partial sums of this layer's BatchNorm backward, when its only consumer's
-                                  # data-gradient kernel produced them (conv_bn(..., input_exclusive=True))
+        self.bn_part = None       # stage-1 partial sums of this layer's BatchNorm backward, when the kernel that wrote the
+                                  # LAST contribution to `grad` produced them (its only consumer's data-gradient kernel,
+                                  # conv_bn(..., input_exclusive=True), or the max-pool backward)
+        self.gives = 0            # gradient contributions received so far; `bn_part` is valid iff bn_part_at == gives
+        self.bn_part_at = -1
 
     @property
     def shape(self):
@@ -99,6 +102,7 @@ class Tape:
             return
         if not act.needs_grad:
             return
+        act.gives += 1
         if act.grad is None:
             act.grad = g
         else:
@@ -165,7 +169,9 @@ class Tape:
                 if not self.training:
                     raise RuntimeError("backward through BatchNorm in eval mode is not supported by the HIP path")
                 inv = self.inv
-                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd, partials=o.bn_part)   # o.grad <- d(raw conv output)
+                # stage-1 rows from the producer of o.grad are only valid if nothing was added to o.grad after them
+                partials = o.bn_part if o.bn_part_at == o.gives else None
+                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd, partials=partials)   # o.grad <- d(raw conv output)
                 o.bn_part = None
                 if self.grad_sink is None and inv != 1.0:
                     # un-scale all BatchNorm parameter gradients with one batched multiply at the end of the backward
@@ -193,7 +199,7 @@ class Tape:
                         part = ops.conv_dgrad_bnred(o.grad, self._pack("conv_dgrad", weight, wf, True), dx, a.raw, a.tx,
                                                     a.bn_rstd)
                     if part is not None:
-                        a.bn_part = part
+                        a.bn_part, a.bn_part_at = part, a.gives + 1      # valid after the _give below and until the next one
                     else:
                         ops.conv_fwd(o.grad, None, lambda lay: self._pack("conv_dgrad", weight, wf, bool(lay)), None, dx,
                                      R, S, 1, R - 1 - pad)
@@ -246,11 +252,20 @@ class Tape:
                     return
                 if a.parts is not None:
                     raise NotImplementedError("pool2 backward into a concat input")
-                if a.grad is None:
+                acc = a.grad is not None
+                if not acc:
                     a.grad = self.alloc(N, H, W, C, device=out.device)
-                    ops.pool2_bwd(o.grad, a.raw, a.tx, a.grad, False)
-                else:
-                    ops.pool2_bwd(o.grad, a.raw, a.tx, a.grad, True)
+                part = None
+                if (a.bn_rstd is not None and a.tx is not None and self.dtype == torch.float16 and _fuse_bnred()
+                        and os.environ.get("UMI_NO_POOLRED_FUSION") != "1"):
+                    # in the encoders built here the pool is the first consumer recorded after the layer it pools, so its
+                    # backward is the LAST contribution to that layer's gradient: it can emit stage 1 of the BatchNorm
+                    # backward reduction on the way (conv_bn's backward checks `gives` and ignores the rows otherwise)
+                    part = ops.pool2_bwd_bnred(o.grad, a.raw, a.tx, a.bn_rstd, a.grad, acc)
+                if part is None:
+                    ops.pool2_bwd(o.grad, a.raw, a.tx, a.grad, acc)
+                a.gives += 1
+                a.bn_part, a.bn_part_at = part, a.gives
             self.steps.append(bwd)
         return o
 

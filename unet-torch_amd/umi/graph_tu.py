@@ -24,6 +24,7 @@ class TUTape(Tape):
     # gradients of a value with several consumers are summed by a libunetmi kernel (no torch arithmetic)
     def _give(self, act, g):
         if act.parts is None and act.needs_grad and act.grad is not None:
+            act.gives += 1
             ops_tu.add(act.grad, g, act.grad)
             return
         super()._give(act, g)

@@ -91,6 +91,9 @@ SIGNATURES = {
     "umi_conv_dgrad_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_bn_bwd_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "umi_pool2_bwd_bnred_stat_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "umi_pool2_bwd_bnred": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                    c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_dice_ce_ws_bytes": (c_size_t, [c_int, c_int, c_long]),
     "umi_dice_ce_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "umi_dice_ce_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),

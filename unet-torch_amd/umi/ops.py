@@ -293,6 +293,23 @@ def pool2_bwd(dpool, x, tx, da, accumulate):
                                   int(accumulate), N, H, W, C, _dt(x), _stream()), "umi_pool2_bwd")
 
 
+def pool2_bwd_bnred(dpool, x, tx, rstd, da, accumulate):
+    """pool2_bwd + stage 1 of the BatchNorm backward of the pooled layer; returns the partial rows, or None when the fused
+    kernel does not take this problem (the caller then runs pool2_bwd and the separate reduction)."""
+    N, H, W, C, ldx = _nhwc(x)
+    rows = L.fn("umi_pool2_bwd_bnred_stat_rows")(N, H, W, C)
+    if rows <= 0 or x.dtype != torch.float16 or tx is None or rstd is None:
+        return None
+    part = torch.empty(rows * 2 * C, dtype=torch.float32, device=x.device)
+    st = L.fn("umi_pool2_bwd_bnred")(dpool.data_ptr(), _nhwc(dpool)[4], x.data_ptr(), ldx, tx.data_ptr(), rstd.data_ptr(),
+                                     da.data_ptr(), _nhwc(da)[4], int(accumulate), part.data_ptr(), N, H, W, C, _dt(x),
+                                     _stream())
+    if st == -2:                                   # UMI_ERR_UNSUPPORTED (alignment / strides): not an error
+        return None
+    L.check(st, "umi_pool2_bwd_bnred")
+    return part
+
+
 _ws_cache = {}
 _ws_high = {}          # device -> largest workspace requested so far
 _ws_pinned = []        # blocks referenced by captured graphs
