@@ -1,7 +1,7 @@
 """Debug aid: per-parameter fp32 gradient error of Model.UNet_attention against the oracle."""
 import os, sys
 import torch
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R, os.path.join(R, "unet-torch_amd")]
 from oracle import recipe, ref_unet
 import Model, loss as L
