@@ -1,5 +1,5 @@
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "unet-torch_amd")]
 import numpy as np, torch
 import Model, loss as L
