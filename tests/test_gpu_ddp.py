@@ -1,0 +1,88 @@
+"""Two ranks on ONE MI355X (gloo collectives on device tensors): the HIP tape's data-parallel path end to end --
+gradients written into the reducer's buckets by the wgrad kernels, all-reduced, handed to the fused optimizer.
+(RCCL needs one GPU per rank; the reducer only sees torch.distributed, so gloo exercises the same code.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import sys
+    import torch.distributed as dist
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [repo, os.path.join(repo, "unet-torch_amd")]
+    import Model
+    import loss as L
+    from umi import ddp, optim as uo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    L.CLASS_NUMBER = 2
+    torch.manual_seed(100)                                         # same replica on both ranks (the broadcast is a no-op)
+    m = Model.UNet(1, 2, 8, compute_dtype="fp32").cuda().train()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 1, 32, 32, generator=g)
+    lab = torch.randint(0, 2, (4, 32, 32), generator=g).float()
+    xs, ls = x[rank * 2:(rank + 1) * 2].cuda(), lab[rank * 2:(rank + 1) * 2].cuda()
+    out = {}
+    # this rank's own gradient, plain tape without the reducer (BatchNorm running statistics restored afterwards)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    L.calc_loss(m(xs), ls, loss_type="dice_bce_mc").backward()
+    out["local"] = [p.grad.detach().cpu().numpy().copy() for p in m.parameters()]
+    m.load_state_dict(sd)
+    m.zero_grad(set_to_none=True)
+    red = ddp.GradReducer(m, world, bucket_mb=0.05)
+    opt = uo.SGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    for step in range(2):
+        loss = L.calc_loss(m(xs), ls, loss_type="dice_bce_mc")
+        opt.zero_grad()
+        loss.backward()
+        red.sync()
+        if step == 0:
+            out["synced"] = [p.grad.detach().cpu().numpy().copy() for p in m.parameters()]
+            out["aliased"] = all(p.grad.data_ptr() == red.buffer_for(p).data_ptr() for p in m.parameters())
+        opt.step()
+    torch.cuda.synchronize()
+    out["params"] = [p.detach().cpu().numpy() for p in m.parameters()]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_hip_tape_gradients_are_averaged_and_replicas_stay_identical():
+    import numpy as np
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    assert a["aliased"] and b["aliased"]                 # the optimizer reads the all-reduced bucket slots, not a stale copy
+    n_diff = 0
+    for la, lb, sa, sb in zip(a["local"], b["local"], a["synced"], b["synced"]):
+        np.testing.assert_allclose(sa, 0.5 * (la + lb), rtol=2e-5, atol=1e-7)  # mean of the two ranks' own gradients
+        np.testing.assert_array_equal(sa, sb)                              # both ranks hold the same reduced gradient
+        n_diff += int(np.abs(la - lb).max() > 0)
+    assert n_diff > 10                                   # the two shards really produced different local gradients
+    for pa, pb in zip(a["params"], b["params"]):
+        np.testing.assert_array_equal(pa, pb)            # replicas identical after two optimizer steps

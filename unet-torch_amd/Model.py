@@ -77,6 +77,7 @@ def _run_tape(module, inputs, build):
                       pack_cache=G.pack_cache_of(module))
         acts = [tape.input_nchw(x, needs_grad=need) for x, need in zip(inputs, in_needs)]
         out_act = build(tape, *acts)
+        tape.finish_forward()
 
         def nchw(o):
             if o.tx is None and o.raw.dtype == torch.float32:

@@ -8,8 +8,9 @@ embedding + position embedding, 12 pre-LN transformer blocks (softmax attention,
 (umi/graph_tu.py) with a hand-written backward; nothing runs through torch.nn.
 
 Keyword-only extra: `compute_dtype` ("fp16" default / "fp32" parity mode, env UMI_COMPUTE_DTYPE).
-Not supported: `vis=True` (attention maps are never materialised), the non-hybrid (pure ViT patch conv) variant,
-the multi-task variants (out of the hot-path scope).
+`VisionTransformerMultitask` / `VisionTransformerMultitaskEM` (reference :444-638): the same encoder with 2 / 6 CUP decoders
+and heads on one tape.
+Not supported: `vis=True` (attention maps are never materialised), the non-hybrid (pure ViT patch conv) variant.
 """
 import copy
 import logging
@@ -305,6 +306,7 @@ class VisionTransformer(nn.Module):
                 y = _build_decoder(tape, h, skips, getattr(self, dname), gh, gw)
                 head = getattr(self, hname)[0]
                 outs.append(tape.conv_bias(y, head.weight, head.bias, out_dtype=torch.float32, pad=head.padding[0]))
+            tape.finish_forward()
             if len(outs) == 1:
                 return tape, [a], outs[0], tape.output_nchw_plain(outs[0])
             return tape, [a], tuple(outs), tuple(tape.output_nchw_plain(o) for o in outs)

@@ -102,6 +102,13 @@ class GradReducer:
         """After loss.backward(): gradients are averaged when this returns (stream-ordered)."""
         if self._marked:
             self.finish()
+            # autograd hands the optimizer a COPY of each gradient taken when the tape returned it (AccumulateGrad clones a
+            # tensor it cannot steal), i.e. before the all-reduce: re-point .grad at the bucket slots, which now hold the
+            # reduced values (no copy; the slots are stable, so the fused optimizer's pointer table never changes either)
+            for b in self.buckets:
+                for p in b.params:
+                    if p.grad is not None:
+                        p.grad = b.views[id(p)]
             self.reset()
             return
         # generic path: the model's backward did not go through the tape

@@ -61,6 +61,7 @@ class Tape:
         self.steps = []
         self.param_grads = {}             # id(param) -> (param, grad tensor)
         self._deferred_unscale = []       # BatchNorm parameter gradients still carrying the loss scale
+        self._nbt = []                    # num_batches_tracked counters of the BatchNorm layers run in training mode
         self._inputs = []
 
     # ---- helpers -----------------------------------------------------------------------
@@ -108,6 +109,12 @@ class Tape:
         else:
             act.grad.add_(g)
 
+    def finish_forward(self):
+        """Host-side bookkeeping batched at the end of the forward pass (one launch instead of one per layer)."""
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
+            self._nbt = []
+
     # ---- graph inputs / outputs --------------------------------------------------------
     def input_nchw(self, x: torch.Tensor, needs_grad=False):
         if not x.is_cuda:
@@ -151,7 +158,7 @@ class Tape:
                                        bn.running_mean if bn.track_running_stats else None,
                                        bn.running_var if bn.track_running_stats else None)
             if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+                self._nbt.append(bn.num_batches_tracked)          # += 1 for all layers in one launch (finish_forward)
             if bias is not None and bn.track_running_stats:
                 bn.running_mean.add_(bias.detach().float(), alpha=mom)      # batch mean of (y + bias) = mean(y) + bias
         else:
@@ -391,7 +398,7 @@ class Tape:
         for a in acts:
             C = a.shape[3]
             assert a.raw.data_ptr() == buf[..., c0:c0 + C].data_ptr(), "concat part is not a slice of the buffer"
-            txs.append(a.tx if a.tx is not None else ops.passthrough_tx(C, buf.device))
+            txs.append(a.tx if a.tx is not None else ops.passthrough_tx_const(C, buf.device))
             parts.append((a, c0, c0 + C))
             c0 += C
         assert c0 == buf.shape[3]

@@ -54,10 +54,24 @@ def _ptr(t):
 
 
 def passthrough_tx(C, device):
-    """Transform rows for channels that are consumed as stored (no BN, no ReLU)."""
+    """Transform rows for channels that are consumed as stored (no BN, no ReLU); a fresh tensor the caller may edit."""
     t = torch.zeros(C, 4, dtype=torch.float32, device=device)
     t[:, 1] = 1.0
     t[:, 3] = NEG_INF
+    return t
+
+
+_passthrough = {}
+
+
+def passthrough_tx_const(C, device):
+    """The same rows as a shared constant, built once per (C, device): for callers that only read / concatenate them."""
+    if torch.cuda.is_current_stream_capturing():
+        return passthrough_tx(C, device)               # not cached: would live in the graph's private pool
+    key = (C, str(device))
+    t = _passthrough.get(key)
+    if t is None:
+        t = _passthrough[key] = passthrough_tx(C, device)
     return t
 
 
