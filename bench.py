@@ -219,6 +219,45 @@ def main():
     # trajectory is bit-identical to the eager one, tests/test_gpu_unet.py).  The W warm-up steps run eagerly before the
     # capture, which itself executes nothing.  Data parallel: eager (the RCCL all-reduce is not captured).
     graphed = None
+    ddp_launch = os.environ.get("UMI_DDP_LAUNCH", "graph")        # "graph": see below; "eager": overlapped all-reduce
+    if world > 1 and not a.eager and ddp_launch == "graph" and os.environ.get("UMI_BENCH_GRAPH", "1") != "0":
+        # Data parallel, host-independent variant: forward + loss + backward are replayed from a HIP graph that writes the
+        # gradients straight into the reducer's flat buckets; the bucket all-reduces (RCCL, eager) and the one-launch
+        # optimizer step follow the replay.  The collectives are then NOT overlapped with the backward pass (124 MB of fp32
+        # gradients: ~1 ms at 8 GPUs); UMI_DDP_LAUNCH=eager selects the overlapped, eagerly issued path instead, which is
+        # faster on a fast host and up to 7 ms/step slower on a slow one (measured on this pool at N=1).
+        from umi.graphs import GraphedStep
+        reducer.deferred = True
+
+        def fwd_bwd(xx, yy):
+            logits = model(xx)
+            loss = L.calc_loss(logits, yy, loss_type="dice_bce_mc")
+            opt.zero_grad()
+            loss.backward()
+            return loss
+        try:
+            graphed = GraphedStep(fwd_bwd, [x, labels], warmup=1)
+
+            trace = os.environ.get("UMI_BENCH_TRACE") == "1"
+
+            def step():
+                t0 = time.perf_counter()
+                loss = graphed(x, labels)
+                t1 = time.perf_counter()
+                reducer.flush()
+                t2 = time.perf_counter()
+                opt.step()
+                if trace and rank == 0:
+                    print(f"[trace] replay {1e3 * (t1 - t0):.1f} ms  flush {1e3 * (t2 - t1):.1f} ms  "
+                          f"opt {1e3 * (time.perf_counter() - t2):.1f} ms (host times)", file=sys.stderr, flush=True)
+                return loss
+            for _ in range(a.warmup):
+                step()
+        except Exception as e:
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            graphed = None
+            reducer.deferred = False
+            torch.cuda.synchronize()
     if world == 1 and not a.eager and os.environ.get("UMI_BENCH_GRAPH", "1") != "0":
         from umi.graphs import GraphedStep
 
@@ -239,6 +278,7 @@ def main():
     if graphed is None:
         for _ in range(a.warmup):
             step()
+    launch = "eager" if graphed is None else ("hipgraph" if world == 1 else "hipgraph(fwd+bwd) + eager all-reduce + optimizer")
 
     def fence():
         torch.cuda.synchronize()
@@ -269,7 +309,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": f"UNet({a.cin},{a.ncls},{a.features}) train step (fwd + dice_bce_mc + bwd + SGD), "
                                    f"{a.size}x{a.size}, batch {a.batch}/GPU, BASELINE configs[1]",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": "hipgraph" if graphed is not None else "eager",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": launch,
                        "algorithmic_tflops_per_gpu": round(3 * gf * a.batch * a.steps / dt / 1e3, 2)},
             "final_loss": round(final_loss, 5),
         }

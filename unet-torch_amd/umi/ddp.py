@@ -45,6 +45,11 @@ class GradReducer:
         self.where = {id(p): b for b in self.buckets for p in b.params}
         self.grad_scale = 1.0 / self.world              # folded into the wgrad output scale by the tape
         self._marked = False
+        # deferred mode (`flush()`): the tape only fills the buckets and launches nothing, so forward + backward can be
+        # captured into a HIP graph (umi.graphs.GraphedStep); the collectives are issued after the replay.  Trades the
+        # overlap with the backward pass (~0.1 ms per 16 MB bucket over xGMI) for a step whose ~350 launches no longer
+        # depend on the host
+        self.deferred = False
         self.reset()
         model._umi_grad_sink = self
         if self.world > 1:
@@ -85,11 +90,28 @@ class GradReducer:
             self._launch(b)
 
     def _launch(self, b):
+        if self.deferred:
+            return
         if self.world > 1 and b.work is None:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def flush(self):
+        """Deferred mode, after the (replayed) backward filled the buckets: all-reduce them, make the stream wait, and point
+        every .grad at its bucket slot (autograd left copies of the un-reduced values there)."""
+        for b in self.buckets:
+            if self.world > 1:
+                # one collective at a time, in bucket order: RCCL runs them back to back on its stream either way (the call
+                # returns once enqueued and makes the compute stream wait); several concurrent 32 MB gloo all-reduces, as used
+                # by the one-GPU rehearsal, take seconds
+                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+            for p in b.params:
+                p.grad = b.views[id(p)]
+        self.reset()
+
     def finish(self):
         """Called at the end of the tape backward: flush stragglers, make the stream wait."""
+        if self.deferred:
+            return
         for b in self.buckets:
             if b.pending > 0 and b.pending < len(b.params):
                 self._launch(b)                         # some parameter of this bucket got no gradient
@@ -102,9 +124,10 @@ class GradReducer:
         """After loss.backward(): gradients are averaged when this returns (stream-ordered)."""
         if self._marked:
             self.finish()
-            # autograd hands the optimizer a COPY of each gradient taken when the tape returned it (AccumulateGrad clones a
-            # tensor it cannot steal), i.e. before the all-reduce: re-point .grad at the bucket slots, which now hold the
-            # reduced values (no copy; the slots are stable, so the fused optimizer's pointer table never changes either)
+            # autograd stores a COPY of each gradient (AccumulateGrad clones a tensor it cannot steal).  The tape's backward
+            # ends with finish(), so that copy is taken after the all-reduce and already holds the reduced values; .grad is
+            # re-pointed at the bucket slots anyway: no copy, and the slots are stable, so the fused optimizer's pointer table
+            # never changes
             for b in self.buckets:
                 for p in b.params:
                     if p.grad is not None:

@@ -140,14 +140,6 @@ PACKERS = {"conv_fwd": pack_conv_fwd, "conv_dgrad": pack_conv_dgrad, "convT_fwd"
            "convT_dgrad": pack_convT_dgrad}
 
 
-def upload_table(arr):
-    """numpy structured array -> (device bytes, pinned host bytes); keep both alive as long as the table is used (a copy
-    recorded during HIP-graph capture reads the host buffer again at every replay)."""
-    import numpy as np
-    host = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()).pin_memory()
-    return host.to("cuda", non_blocking=True), host
-
-
 class PackCache:
     """Kernel-layout fp16/fp32 copies of a model's convolution weights, owned by the top-level module.
 
@@ -161,6 +153,38 @@ class PackCache:
     def __init__(self):
         self.ents = {}
         self._tables = {}          # tuple(entry keys) -> (device table, host table, total_blocks, n)
+
+    _CAP = 1 << 18                     # bytes of descriptor-table space (a U-Net's table is 3 KB)
+
+    def _buffers(self):
+        """Pinned staging + device space for the descriptor tables, allocated once and OUTSIDE any HIP-graph capture (the
+        first forward of a model is never captured: GraphedStep warms up first).  Tables are appended and never rewritten,
+        and travel to the device with umi_table_upload (a kernel reading the device-mapped pinned memory): inside a capture
+        that is an ordinary kernel node which re-reads the same, unchanged, bytes at every replay."""
+        if getattr(self, "_dev", None) is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("PackCache: first use inside a HIP-graph capture; run one eager forward first")
+            self._dev = torch.empty(self._CAP, dtype=torch.uint8, device="cuda")
+            self._host = torch.empty(self._CAP, dtype=torch.uint8).pin_memory()
+            self._used = 0
+        return self._host, self._dev
+
+    def _upload(self, arr):
+        import numpy as np
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        nbytes = (raw.size + 15) // 16 * 16
+        host, dev = self._buffers()
+        if self._used + nbytes > self._CAP:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("PackCache: descriptor-table space exhausted during a HIP-graph capture")
+            torch.cuda.current_stream().synchronize()          # nothing in flight may still read the old tables
+            self._tables.clear()
+            self._used = 0
+        off = self._used
+        host.numpy()[off:off + raw.size] = raw
+        L.check(L.fn("umi_table_upload")(host.data_ptr() + off, dev.data_ptr() + off, nbytes, _stream()), "umi_table_upload")
+        self._used = off + nbytes
+        return dev.data_ptr() + off
 
     def __deepcopy__(self, memo):      # a copied / pickled module starts with an empty cache
         return PackCache()
@@ -184,7 +208,9 @@ class PackCache:
             T, K, N = e.args[:3]
             e.dst = torch.empty(T * K * N, dtype=dtype, device=w.device)
             self.ents[key] = e
-            self._tables.clear()
+            if not torch.cuda.is_current_stream_capturing():
+                self._buffers()
+            # (tables built for the previous entry set stay where they are: a captured graph may still replay them)
         ver = self._ver(w)
         if e.ver != ver:
             T, K, N, st, sk, sn, flip = e.args
@@ -197,14 +223,17 @@ class PackCache:
     def refresh(self):
         """Re-pack every stale entry (one launch per storage dtype)."""
         import numpy as np
+        force = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         stale = {}
         for key, e in list(self.ents.items()):
             w = e.w()
             if w is None:
                 del self.ents[key]
-                self._tables.clear()
                 continue
-            if e.ver != self._ver(w):
+            # inside a HIP-graph capture every entry is re-packed: the replayed graph must refresh the copies itself, whatever
+            # the parameter versions were when it was captured (e.g. a captured forward + backward whose optimizer step runs
+            # outside the graph: nothing is stale at capture time, everything is at the second replay)
+            if force or e.ver != self._ver(w):
                 stale.setdefault(e.dst.dtype, []).append((key, e, w))
         blk = None
         for dtype, items in stale.items():
@@ -218,10 +247,9 @@ class PackCache:
                     T, K, N, st, sk, sn, flip = e.args
                     arr[i] = (w.data_ptr(), e.dst.data_ptr(), st, sk, sn, T, K, N, flip, K, N, int(e.k8), b0)
                     b0 += (T * K * N + blk - 1) // blk
-                dev, host = upload_table(arr)
-                tab = self._tables[tkey] = (dev, host, b0, len(items))
-            dev, _, total, n = tab
-            L.check(L.fn("umi_pack_kn_multi")(dev.data_ptr(), n, total, L.UMI_F32 if dtype == torch.float32 else L.UMI_F16,
+                tab = self._tables[tkey] = (self._upload(arr), b0, len(items))
+            dev_ptr, total, n = tab
+            L.check(L.fn("umi_pack_kn_multi")(dev_ptr, n, total, L.UMI_F32 if dtype == torch.float32 else L.UMI_F16,
                                               _stream()), "umi_pack_kn_multi")
             for _, e, w in items:
                 e.ver = self._ver(w)
