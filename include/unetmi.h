@@ -120,6 +120,11 @@ int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, void* da, in
  * emits stage 1 of the BatchNorm backward of the pooled layer (x = its raw output, tx / rstd its transform and 1/std):
  * part[rows][2][C], rows = umi_pool2_bwd_bnred_stat_rows().  fp16, even H and W, C % 8 == 0; else UMI_ERR_UNSUPPORTED
  * (caller uses umi_pool2_bwd + umi_bn_bwd_reduce). */
+/* BatchNorm batch statistics of a stored fp16 tensor (for a producer without a statistics epilogue: the pointwise MFMA conv
+ * of the attention gates, reference Model.py:268-289): part[rows][2][C] = per-block sums / sums of squares, the layout
+ * umi_bn_finalize consumes; rows = umi_bn_stats_rows(M, C) (0 = unsupported: C % 8 != 0). */
+int umi_bn_stats_rows(long M, int C);
+int umi_bn_stats(const void* x, int ldx, float* part, long M, int C, int dtype, umi_stream_t stream);
 int umi_pool2_bwd_bnred_stat_rows(int N, int H, int W, int C);
 int umi_pool2_bwd_bnred(const void* dpool, int lddp, const void* x, int ldx, const void* tx, const float* rstd, void* da,
                         int ldda, int accumulate, float* part, int N, int H, int W, int C, int dtype, umi_stream_t stream);

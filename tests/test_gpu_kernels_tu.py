@@ -290,3 +290,45 @@ def test_bilinear_pool_gn_fp16_vector_paths():
     _close(dx.permute(0, 3, 1, 2), xr.grad, 4e-2)
     _close(dg, gr.grad, 2e-2)
     _close(db, br.grad, 2e-2)
+
+
+@pytest.mark.parametrize("case", [(2, 9, 13, 128, 32, True), (1, 16, 16, 32, 128, False), (2, 7, 5, 96, 40, True),
+                                  (1, 20, 20, 64, 64, True), (1, 8, 8, 16, 16, False)])
+def test_pointwise_mfma_partial_tiles_and_bn_stats_pass(case):
+    """Plain 1x1 conv on the MFMA kernel with channel counts that are only multiples of 8 (partial last K chunk / partial
+    output tile: the attention gates' 32-channel branches), against torch and the generic kernel; and umi_bn_stats (the
+    separate BatchNorm statistics pass used when the producer has no statistics epilogue) against torch sums."""
+    lib, ops, T = _gpu()
+    N, H, W, Ci, Co, use_tx = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(N, H, W, Ci, generator=g).half()
+    w = torch.randn(Co, Ci, 1, 1, generator=g) * (2.0 / Ci) ** 0.5
+    t = None
+    if use_tx:
+        t = torch.empty(Ci, 4)
+        t[:, 0] = 0.1 * torch.randn(Ci, generator=g)
+        t[:, 1] = 0.5 + torch.rand(Ci, generator=g)
+        t[:, 2] = 0.2 * torch.randn(Ci, generator=g)
+        t[:, 3] = 0.0
+    a = x.float() if t is None else torch.maximum(x.float() * t[:, 1] + t[:, 2], t[:, 3])
+    ref = torch.nn.functional.conv2d(a.permute(0, 3, 1, 2), w.half().float()).permute(0, 2, 3, 1)
+    xd, wd = x.to(DEV), w.to(DEV)
+    td = t.to(DEV).contiguous() if t is not None else None
+    outs = {}
+    for name, flags in (("mfma", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        y = torch.full((N, H, W, Co + 8), 7.0, device=DEV, dtype=torch.float16)[..., :Co]      # channel slice: ld > Co
+        lay, _ = ops.conv_plan(xd, y, 1, 1, 1, 0, flags)
+        assert lay == (1 if name == "mfma" else 0)
+        ops.conv_fwd(xd, td, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), None, y, 1, 1, 1, 0, flags=flags)
+        outs[name] = y.float().cpu()
+        assert float(y._base[..., Co:].min()) == 7.0 if y._base is not None else True           # nothing written past Co
+    scale = ref.abs().max().item()
+    assert (outs["mfma"] - ref).abs().max().item() < 4e-3 * scale
+    assert (outs["generic"] - ref).abs().max().item() < 4e-3 * scale
+    yd = outs["mfma"].half().to(DEV)
+    part = ops.bn_stats(yd)
+    assert part is not None
+    sums = part.view(-1, 2, Co).sum(0).cpu()
+    yf = outs["mfma"].half().float().reshape(-1, Co)
+    torch.testing.assert_close(sums[0], yf.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-3)

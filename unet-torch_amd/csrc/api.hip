@@ -130,6 +130,19 @@ extern "C" int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, v
 }
 
 // stage 2 of the BatchNorm backward reduction on partial rows produced by umi_conv_dgrad_bnred
+int umi_colsum_rows_f16v(long M, int C);
+bool umi_bn_stats_f16v(const void* x, int ldx, float* part, long M, int C, hipStream_t s);
+
+// BatchNorm batch statistics of a stored fp16 tensor as partial rows part[rows][2][C] (sum, sum of squares) for umi_bn_finalize:
+// for producers without a statistics epilogue (the pointwise MFMA convolution).  rows = umi_bn_stats_rows(M, C) (0: unsupported).
+extern "C" int umi_bn_stats_rows(long M, int C) { return umi_colsum_rows_f16v(M, C); }
+extern "C" int umi_bn_stats(const void* x, int ldx, float* part, long M, int C, int dtype, umi_stream_t stream) {
+    if (!x || !part || M <= 0 || C <= 0 || ldx < C) return UMI_ERR_BADARG;
+    if (dtype != UMI_F16 || !umi_bn_stats_f16v(x, ldx, part, M, C, (hipStream_t)stream)) return UMI_ERR_UNSUPPORTED;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
 int umi_pool2_bwd_bnred_rows(int N, int H, int W, int C);
 bool umi_pool2_bwd_bnred_f16v(const void* dp, int lddp, const void* x, int ldx, const void* tx, const float* rstd, void* da,
                               int ldda, int accumulate, float* part, int N, int H, int W, int C, hipStream_t s);

@@ -82,9 +82,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         }
     }
     long woff[KPW];                           // element offset of weight row k (chunk 0)
+    bool wv[KPW];                             // output channel exists (plain mode accepts Co % 8 == 0: the last tile is partial)
+    const int Ntot_ = OUT_UPS ? 4 * Nc : Nc;
 #pragma unroll
     for (int k = 0; k < KPW; ++k) {
         int cop = c0 + (tid >> 3) + 32 * k;   // output channel index in [0, taps_out * Nc)
+        wv[k] = cop < Ntot_;
+        if (!wv[k]) cop = c0;                 // keep the address in range; the row is staged as zeros
         int tap = OUT_UPS ? cop / Nc : 0;
         int co = cop - tap * Nc;
         // OUT_UPS : wp8 = [4][Kc/8][Nc][8]  (tap of the OUTPUT);   GATHER: wp8 = [R*S][Kc/8][Nc][8] (tap of the INPUT)
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
 
-    const int chunks_per_tap = Kc / CK;
+    const int chunks_per_tap = (Kc + CK - 1) / CK;        // plain mode accepts Kc % 8 == 0: the last chunk is partial
     const int nchunks = GATHER ? ntaps * chunks_per_tap : chunks_per_tap;
 #define UMI_ISSUE(c_)                                                                                              \
     do {                                                                                                          \
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         const int kc = cc - tap_in * chunks_per_tap;                                                              \
         const long xadd = (long)kc * CK;                                                                          \
         const long wadd = ((long)tap_in * (Kc >> 3) + kc * 8) * Nc * 8;                                           \
+        const bool kin = kc * CK + sub * 8 < Kc;      /* this thread's 8 input channels exist in the chunk */     \
         if (GATHER) {                                                                                             \
             const int ty = tap_in / geo.S, tx_ = tap_in - ty * geo.S;                                             \
             _Pragma("unroll") for (int k = 0; k < KPX; ++k) {                                                     \
@@ -134,17 +139,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
             }                                                                                                     \
         } else {                                                                                                  \
             _Pragma("unroll") for (int k = 0; k < KPX; ++k)                                                       \
-                xraw[k] = xoff[k] >= 0 ? *reinterpret_cast<const half8*>(x + xoff[k] + xadd) : zero8;             \
+                xraw[k] = (xoff[k] >= 0 && kin) ? *reinterpret_cast<const half8*>(x + xoff[k] + xadd) : zero8;    \
         }                                                                                                         \
         _Pragma("unroll") for (int k = 0; k < KPW; ++k)                                                           \
-            wraw[k] = *reinterpret_cast<const half8*>(wp8 + woff[k] + wadd);                                      \
+            wraw[k] = (wv[k] && kin) ? *reinterpret_cast<const half8*>(wp8 + woff[k] + wadd) : zero8;             \
     } while (0)
 
     const int lrow = lane & 15, lgrp = lane >> 4;
     const int b_base = (wm * NT * 32 + lrow) * ROWB + lgrp * 16;          // + pt*16*ROWB + ks*64
     const int a_base = XB + (wn * 64 + lrow) * ROWB + lgrp * 16;          // + ct*16*ROWB + ks*64
 
-#define UMI_TXROW(cc_) (tx[(GATHER ? (cc_) % chunks_per_tap : (cc_)) * CK + tid])
+#define UMI_TXROW(cc_)                                                                                            \
+    (((GATHER ? (cc_) % chunks_per_tap : (cc_)) * CK + tid) < Kc ? tx[(GATHER ? (cc_) % chunks_per_tap : (cc_)) * CK + tid] \
+                                                                : make_float4(0.f, 1.f, 0.f, 0.f))
     float4 txr = make_float4(0.f, 1.f, 0.f, 0.f);
     if (HAS_TX) {
         if (tid < CK) {
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
             for (int j = 0; j < 8; ++j) t[j] = txbuf[c & 1][j * 8 + sub];
 #pragma unroll
             for (int k = 0; k < KPX; ++k)
-                if (xv[k]) {
+                if (xv[k] && c * CK % (chunks_per_tap * CK) + sub * 8 < Kc) {
                     xraw[k] = umi_tx8(xraw[k], t);
                 }
         }
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int cop = c0 + col + j;
-                bv[j] = bias[OUT_UPS ? cop % Nc : cop];
+                bv[j] = cop < Ntot_ ? bias[OUT_UPS ? cop % Nc : cop] : 0.f;
             }
         }
 #pragma unroll
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     {
         const int j = tid % PPR, p0 = tid / PPR;
         const int cop = c0 + j * 8;
+        const bool col_ok = cop < Ntot_;
         int co = cop, tdy = 0, tdx = 0;
         if (OUT_UPS) {
             const int tap = cop / Nc;
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         }
 #pragma unroll 4
         for (int p = p0; p < P; p += PSTEP) {
-            if (m0 + p >= M) break;
+            if (m0 + p >= M || !col_ok) break;
             const int2 pi = pixinfo[p];
             int yy = pi.y >> 16, xx = pi.y & 0xffff;
             if (OUT_UPS) {
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 template <int P, int BN>
 int launch(bool s2d, bool ups, const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y,
            int ldy, long M, int Kc, int Nc, int Ntot, int ntaps, Geo geo, hipStream_t s) {
-    const int n_co = Ntot / BN;
+    const int n_co = (Ntot + BN - 1) / BN;
     const long nblk = ((M + P - 1) / P) * n_co;
     dim3 grid((unsigned)nblk), block(256);
 #define GO(S2D, UPS, HT)                                                                                          \
@@ -289,7 +297,11 @@ bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int 
     if (in_dtype != UMI_F16 || out_dtype != UMI_F16) return false;
     const int mode = umi_conv1x1_mode(R, S, stride, pad, flags);
     if (mode < 0) return false;
-    if (Ci % 64 || Co % 64 || ldx % 8 || ldy % 8) return false;
+    if (ldx % 8 || ldy % 8) return false;
+    // plain 1x1: any Ci, Co that are multiples of 8 (partial last K chunk / output tile; the attention gates' 32-channel
+    // branches); the tap-gather / transposed-conv modes keep whole 64-channel tiles
+    if (mode == 0) return Ci % 8 == 0 && Co % 8 == 0 && Ci >= 16 && Co >= 16;
+    if (Ci % 64 || Co % 64) return false;
     return true;
 }
 

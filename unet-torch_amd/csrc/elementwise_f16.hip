@@ -74,9 +74,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce1_v8(const half_t* __restric
 }
 
 // ---- per-channel column sums (bias gradients: ConvTranspose2d / Linear biases), stage 1 -------------------------------
+// SQ: also the per-channel sums of squares (slot 1 of the partial rows): BatchNorm statistics of a tensor whose producer has
+// no statistics epilogue (the pointwise MFMA convolution of the attention gates)
+template <bool SQ = false>
 __global__ __launch_bounds__(256) void colsum_v8(const half_t* __restrict__ x, int ldx, float* __restrict__ ws, long M, int C,
                                                  int RPB) {
     __shared__ float red[256][9];
+    float q0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x;
     // channel groups of 8: this workgroup covers groups [gb, gb + Gb) (any C % 8 == 0: blockIdx.y walks 256 groups at a time,
     // a group count that does not divide 256 leaves the tail threads idle)
@@ -98,12 +102,18 @@ __global__ __launch_bounds__(256) void colsum_v8(const half_t* __restrict__ x, i
             half8 c = *reinterpret_cast<const half8*>(x + (r + 2 * PL) * ldx + cg * 8);
             half8 d = *reinterpret_cast<const half8*>(x + (r + 3 * PL) * ldx + cg * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s0[j] += (float)a[j] + (float)c[j]; s1[j] += (float)b[j] + (float)d[j]; }
+            for (int j = 0; j < 8; ++j) {
+                s0[j] += (float)a[j] + (float)c[j]; s1[j] += (float)b[j] + (float)d[j];
+                if (SQ) {
+                    const float fa = (float)a[j], fb = (float)b[j], fc = (float)c[j], fd = (float)d[j];
+                    q0[j] = fmaf(fa, fa, fmaf(fb, fb, fmaf(fc, fc, fmaf(fd, fd, q0[j]))));
+                }
+            }
         }
         for (; r < r1; r += PL) {
             half8 a = *reinterpret_cast<const half8*>(x + r * ldx + cg * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s0[j] += (float)a[j];
+            for (int j = 0; j < 8; ++j) { s0[j] += (float)a[j]; if (SQ) q0[j] = fmaf((float)a[j], (float)a[j], q0[j]); }
         }
     }
 #pragma unroll
@@ -113,6 +123,17 @@ __global__ __launch_bounds__(256) void colsum_v8(const half_t* __restrict__ x, i
         float a = 0.f;
         for (int k = 0; k < PL; ++k) a += red[k * Gb + (cl >> 3)][cl & 7];
         ws[((long)blockIdx.x * 2 + 0) * C + gb * 8 + cl] = a;
+    }
+    if (SQ) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid][j] = q0[j];
+        __syncthreads();
+        for (int cl = tid; cl < Gb * 8; cl += 256) {
+            float a = 0.f;
+            for (int k = 0; k < PL; ++k) a += red[k * Gb + (cl >> 3)][cl & 7];
+            ws[((long)blockIdx.x * 2 + 1) * C + gb * 8 + cl] = a;
+        }
     }
 }
 
@@ -307,8 +328,16 @@ int umi_colsum_rows_f16v(long M, int C) { return (C % 8 == 0) ? (int)((M + rpb_c
 bool umi_colsum_f16v(const void* x, int ldx, float* ws, long M, int C, hipStream_t s) {
     if (!umi_colsum_rows_f16v(M, C) || ldx % 8 || !al16(x)) return false;
     const int rpb = rpb_colsum(M, C);
-    hipLaunchKernelGGL(colsum_v8, dim3((unsigned)((M + rpb - 1) / rpb), (C / 8 + 255) / 256), dim3(256), 0, s, (const half_t*)x, ldx, ws,
+    hipLaunchKernelGGL(colsum_v8<false>, dim3((unsigned)((M + rpb - 1) / rpb), (C / 8 + 255) / 256), dim3(256), 0, s, (const half_t*)x, ldx, ws,
                        M, C, rpb);
+    return true;
+}
+// BatchNorm statistics pass: part[rows][2][C] = per-block sums and sums of squares of x (rows = umi_colsum_rows_f16v)
+bool umi_bn_stats_f16v(const void* x, int ldx, float* part, long M, int C, hipStream_t s) {
+    if (!umi_colsum_rows_f16v(M, C) || ldx % 8 || !al16(x)) return false;
+    const int rpb = rpb_colsum(M, C);
+    hipLaunchKernelGGL(colsum_v8<true>, dim3((unsigned)((M + rpb - 1) / rpb), (C / 8 + 255) / 256), dim3(256), 0, s, (const half_t*)x, ldx,
+                       part, M, C, rpb);
     return true;
 }
 

@@ -148,10 +148,19 @@ class Tape:
         if out is None:
             out = self.alloc(N, Ho, Wo, Co, device=a.raw.device)
         wf = weight.detach().float()
-        # the pointwise matrix-core kernel has no statistics epilogue: 1x1 convs that feed a BatchNorm take the generic one
-        flags = L.CONV_FORCE_GENERIC if (self.training and (R, S) == (1, 1)) else 0
-        part = ops.conv_fwd(a.raw, a.tx, lambda lay: self._pack("conv_fwd", weight, wf, bool(lay)), None, out,
-                            R, S, stride, pad, want_stats=self.training, flags=flags)
+        # the pointwise matrix-core kernel has no statistics epilogue: a 1x1 conv that feeds a BatchNorm (attention gates) runs
+        # it without statistics and takes them in a separate HBM-bound pass over its (small: C_hidden channels) output; where
+        # neither applies (odd channel counts, the 1-channel psi conv) the generic kernel produces both
+        part, flags, two_pass = None, 0, False
+        if self.training and (R, S) == (1, 1):
+            two_pass = (self.dtype == torch.float16 and Co % 8 == 0 and
+                        ops.conv_plan(a.raw, out, R, S, stride, pad, 0, False)[0] == 1)
+            flags = 0 if two_pass else L.CONV_FORCE_GENERIC
+        res = ops.conv_fwd(a.raw, a.tx, lambda lay: self._pack("conv_fwd", weight, wf, bool(lay)), None, out,
+                           R, S, stride, pad, want_stats=self.training and not two_pass, flags=flags)
+        part = ops.bn_stats(out) if two_pass else res
+        if self.training and part is None:
+            raise RuntimeError("conv_bn: no BatchNorm statistics were produced for this layer")
         if self.training:
             mom = bn.momentum if bn.momentum is not None else 0.1
             tx, rstd = ops.bn_finalize(part, Co, N * Ho * Wo, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,

@@ -335,6 +335,21 @@ def pool2_bwd(dpool, x, tx, da, accumulate):
                                   int(accumulate), N, H, W, C, _dt(x), _stream()), "umi_pool2_bwd")
 
 
+def bn_stats(y):
+    """Statistics partials [rows][2][C] of a stored tensor (for bn_finalize), or None when the kernel does not apply."""
+    N, H, W, C, ldy = _nhwc(y)
+    M = N * H * W
+    rows = L.fn("umi_bn_stats_rows")(M, C) if y.dtype == torch.float16 else 0
+    if rows <= 0:
+        return None
+    part = torch.empty(rows * 2 * C, dtype=torch.float32, device=y.device)
+    st = L.fn("umi_bn_stats")(y.data_ptr(), ldy, part.data_ptr(), M, C, _dt(y), _stream())
+    if st == -2:
+        return None
+    L.check(st, "umi_bn_stats")
+    return part
+
+
 def pool2_bwd_bnred(dpool, x, tx, rstd, da, accumulate):
     """pool2_bwd + stage 1 of the BatchNorm backward of the pooled layer; returns the partial rows, or None when the fused
     kernel does not take this problem (the caller then runs pool2_bwd and the separate reduction)."""
