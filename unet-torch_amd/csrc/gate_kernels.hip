@@ -10,6 +10,7 @@
 // One wave owns a pixel at a time: lanes stride over the channels (coalesced), the per-pixel reduction of the backward
 // is a wave shuffle.  Pixels are independent -> grid-stride over pixels, >> 256 workgroups at the sizes of interest.
 #include "common.h"
+#include <stdint.h>
 
 namespace {
 
@@ -85,6 +86,78 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dy,
     }
 }
 
+// 16-B vectorised variants (fp16, C % 8 == 0, C/8 a power of two <= 64): a pixel's channels sit on C/8 consecutive lanes,
+// 64 / (C/8) pixels per wave; the backward's per-pixel sum is a butterfly over those lanes.
+typedef _Float16 half8g __attribute__((ext_vector_type(8)));
+
+template <bool HAS_TX>
+__global__ __launch_bounds__(256) void gate_fwd_v8(const half_t* __restrict__ x, int ldx, const float4* __restrict__ txx,
+                                                   const half_t* __restrict__ p, const float4* __restrict__ txp,
+                                                   half_t* __restrict__ y, int ldy, long M, int G) {
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);
+    const long stride = ((long)gridDim.x * 256) / G;
+    const float4 tp = txp ? txp[0] : make_float4(0.f, 1.f, 0.f, -INFINITY);
+    float4 t[8];
+    if (HAS_TX) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = txx[cg * 8 + j];
+    }
+    for (long m = gt / G; m < M; m += stride) {
+        const float A = sigmoidf_(txf((float)p[m], tp));
+        const half8g v = *reinterpret_cast<const half8g*>(x + m * ldx + cg * 8);
+        half8g o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j];
+            if (HAS_TX) f = txf(f, t[j]);
+            o[j] = (half_t)(f * A);
+        }
+        *reinterpret_cast<half8g*>(y + m * ldy + cg * 8) = o;
+    }
+}
+
+template <bool HAS_TX>
+__global__ __launch_bounds__(256) void gate_bwd_v8(const half_t* __restrict__ dy, int lddy, const half_t* __restrict__ x, int ldx,
+                                                   const float4* __restrict__ txx, const half_t* __restrict__ p,
+                                                   const float4* __restrict__ txp, half_t* __restrict__ dx, int lddx,
+                                                   half_t* __restrict__ dp, long M, int G) {
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);
+    const long stride = ((long)gridDim.x * 256) / G;
+    const float4 tp = txp ? txp[0] : make_float4(0.f, 1.f, 0.f, -INFINITY);
+    float4 t[8];
+    if (HAS_TX) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = txx[cg * 8 + j];
+    }
+    // every lane of a pixel's group runs the same number of trips (M and the stride are the same for all of them), so the
+    // butterfly below always finds its partners
+    for (long m = gt / G; m < M; m += stride) {
+        const float A = sigmoidf_(txf((float)p[m], tp));
+        const half8g g = *reinterpret_cast<const half8g*>(dy + m * lddy + cg * 8);
+        const half8g v = *reinterpret_cast<const half8g*>(x + m * ldx + cg * 8);
+        half8g o;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j];
+            if (HAS_TX) f = txf(f, t[j]);
+            acc = fmaf((float)g[j], f, acc);
+            o[j] = (half_t)((float)g[j] * A);
+        }
+        *reinterpret_cast<half8g*>(dx + m * lddx + cg * 8) = o;
+        for (int w = G >> 1; w > 0; w >>= 1) acc += __shfl_xor(acc, w, 64);
+        if (cg == 0) dp[m] = (half_t)(acc * A * (1.f - A));
+    }
+}
+
+inline bool gate_vec_ok(int C, int l0, int l1, int l2, const void* a, const void* b, const void* c) {
+    const int G = C / 8;
+    if (C % 8 || G > 64 || (G & (G - 1)) || l0 % 8 || l1 % 8 || l2 % 8) return false;
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
+
 inline int ew_grid(long work_items, int per_block) {
     long g = (work_items + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -128,6 +201,15 @@ extern "C" int umi_gate_fwd(const void* x, int ldx, const void* txx, const void*
                             int C, int dtype, umi_stream_t stream) {
     if (!x || !p || !y || M <= 0 || C <= 0 || ldx < C || ldy < C) return UMI_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F16 && gate_vec_ok(C, ldx, ldy, 8, x, y, x)) {
+        const int G = C / 8, g2 = ew_grid(M * G, 256 * 4);
+        if (txx) hipLaunchKernelGGL(gate_fwd_v8<true>, dim3(g2), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txx,
+                                    (const half_t*)p, (const float4*)txp, (half_t*)y, ldy, M, G);
+        else hipLaunchKernelGGL(gate_fwd_v8<false>, dim3(g2), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txx,
+                                (const half_t*)p, (const float4*)txp, (half_t*)y, ldy, M, G);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     const int grid = ew_grid(M, 4 * 4);                  // 4 waves per block, ~4 pixels per wave
     if (dtype == UMI_F16)
         hipLaunchKernelGGL(gate_fwd_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txx,
@@ -144,6 +226,15 @@ extern "C" int umi_gate_bwd(const void* dy, int lddy, const void* x, int ldx, co
                             void* dx, int lddx, void* dp, long M, int C, int dtype, umi_stream_t stream) {
     if (!dy || !x || !p || !dx || !dp || M <= 0 || C <= 0 || lddy < C || ldx < C || lddx < C) return UMI_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F16 && gate_vec_ok(C, lddy, ldx, lddx, dy, x, dx)) {
+        const int G = C / 8, g2 = ew_grid(M * G, 256 * 4);
+        if (txx) hipLaunchKernelGGL(gate_bwd_v8<true>, dim3(g2), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)x, ldx,
+                                    (const float4*)txx, (const half_t*)p, (const float4*)txp, (half_t*)dx, lddx, (half_t*)dp, M, G);
+        else hipLaunchKernelGGL(gate_bwd_v8<false>, dim3(g2), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)x, ldx,
+                                (const float4*)txx, (const half_t*)p, (const float4*)txp, (half_t*)dx, lddx, (half_t*)dp, M, G);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     const int grid = ew_grid(M, 4 * 4);
     if (dtype == UMI_F16)
         hipLaunchKernelGGL(gate_bwd_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)x, ldx,
