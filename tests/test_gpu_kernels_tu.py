@@ -332,3 +332,27 @@ def test_pointwise_mfma_partial_tiles_and_bn_stats_pass(case):
     yf = outs["mfma"].half().float().reshape(-1, Co)
     torch.testing.assert_close(sums[0], yf.sum(0), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(2 * 9 * 13, 128, 32), (400, 32, 128), (70, 96, 40), (256, 16, 16)])
+def test_wgrad1x1_mfma_partial_channel_tiles(shape):
+    """Weight gradient of a plain 1x1 conv on the MFMA kernel with channel counts that are only multiples of 8 (attention
+    gates: 32 hidden channels): against torch and the generic kernel; the elements next to the tensors must not matter."""
+    lib, ops, T = _gpu()
+    M, Ci, Co = shape
+    g = torch.Generator().manual_seed(M + Ci)
+    xb = torch.randn(1, 1, M + 3, Ci, generator=g).half()          # extra rows: what a partial tile reads past the channels
+    dyb = (torch.randn(1, 1, M + 3, Co, generator=g) * 0.1).half()
+    xb[0, 0, M:] = float("nan")
+    dyb[0, 0, M:] = float("nan")
+    x, dy = xb[:, :, :M], dyb[:, :, :M]
+    ref = dy[0, 0].float().t() @ x[0, 0].float()
+    res = {}
+    for name, flags in (("mfma", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        gw = torch.full((Co, Ci), 7.0, device=DEV)
+        ops.conv_wgrad(xb.to(DEV)[:, :, :M], None, dyb.to(DEV)[:, :, :M], None, gw, Ci, 1, 1, 1.0, 1, 1, 1, 0, flags=flags)
+        res[name] = gw.cpu()
+    scale = ref.abs().max().item()
+    assert torch.isfinite(res["mfma"]).all()
+    assert (res["generic"] - ref).abs().max().item() < 2e-3 * scale
+    assert (res["mfma"] - ref).abs().max().item() < 4e-3 * scale

@@ -699,7 +699,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
     const int wci = wave >> 1, wco = wave & 1;
     const int ci0 = (blockIdx.x / n_co_t) * TM, co0 = (blockIdx.x % n_co_t) * TM;
     if (HAS_TX) {
-        if (tid < TM) txs[(tid & 7) * PPP + (tid >> 3)] = tx[ci0 + tid];     // transposed [j][sub]: conflict-free reads
+        // transposed [j][sub]: conflict-free reads; rows past Ci (partial channel tile) are the identity
+        if (tid < TM) txs[(tid & 7) * PPP + (tid >> 3)] = ci0 + tid < Ci ? tx[ci0 + tid] : make_float4(0.f, 1.f, 0.f, 0.f);
         __syncthreads();
     }
     const int t_begin = blockIdx.y * tiles_per_split;
@@ -796,18 +797,21 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
     for (int ta = 0; ta < T16; ++ta)
 #pragma unroll
         for (int tb = 0; tb < T16; ++tb) {
+            // channel counts that are only multiples of 8 (plain 1x1 mode): the operands of the missing channels were read
+            // from whatever follows in memory (or zeros past the end), which only reaches accumulators that are not stored
             const int co = co0 + (wco * T16 + tb) * 16 + (lane & 15);
+            if (co >= Co) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci0 + (wci * T16 + ta) * 16 + 4 * (lane >> 4) + r;
-                part[(((long)blockIdx.y * gridDim.z + blockIdx.z) * Ci + ci) * Co + co] = acc[ta][tb][r];
+                if (ci < Ci) part[(((long)blockIdx.y * gridDim.z + blockIdx.z) * Ci + ci) * Co + co] = acc[ta][tb][r];
             }
         }
 }
 
 void plan1(long M, int Ci, int Co, int TM, int* tiles_total, int* splits, int* tps, int taps = 1) {
     *tiles_total = (int)((M + 63) / 64);
-    const long pairs = (long)(Ci / TM) * (Co / TM) * taps;
+    const long pairs = (long)((Ci + TM - 1) / TM) * ((Co + TM - 1) / TM) * taps;
     static const long target2 = [] { const char* e = getenv("UMI_WGRAD_SPLIT_TARGET2"); long v = e ? atol(e) : 0; return v > 0 ? v : 1024L; }();
     long want = (target2 + pairs - 1) / pairs;
     const long slab = (long)taps * Ci * Co * 4;
@@ -828,7 +832,7 @@ bool umi_wgrad1x1_mfma_ok(long M, int Ci, int Co, int R, int S, int stride, int 
     if (flags & UMI_CONV_FORCE_GENERIC) return false;
     if (dtype != UMI_F16 || txb) return false;
     if (R != 1 || S != 1 || stride != 1 || pad != 0) return false;
-    if (Ci % 64 || Co % 64 || ldx % 8 || lddy % 8) return false;
+    if (Ci % 8 || Co % 8 || Ci < 16 || Co < 16 || ldx % 8 || lddy % 8) return false;   // partial 64-channel tiles are masked
     if (M * (long)(ldx > lddy ? ldx : lddy) * 2 >= 0x7FFFFFF0L) return false;     // 32-bit buffer offsets
     return true;
 }
@@ -852,8 +856,8 @@ int umi_wgrad1x1_mfma(const void* x, int ldx, const void* txa, const void* dy, i
     plan1(M, Ci, Co, TM, &tt, &splits, &tps);
     if (ws_bytes < (size_t)splits * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
-    const int n_co_t = Co / TM;
-    dim3 grid((Ci / TM) * n_co_t, splits), block(256);
+    const int n_co_t = (Co + TM - 1) / TM;
+    dim3 grid(((Ci + TM - 1) / TM) * n_co_t, splits), block(256);
     const WGeo geo{1, 1, 1, 1, 1, 1, 0};
 #define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_, false>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t, geo)
     if (TM == 128) { if (txa) GO(128, true); else GO(128, false); }
