@@ -219,15 +219,20 @@ def main():
     # trajectory is bit-identical to the eager one, tests/test_gpu_unet.py).  The W warm-up steps run eagerly before the
     # capture, which itself executes nothing.  Data parallel: eager (the RCCL all-reduce is not captured).
     graphed = None
-    ddp_launch = os.environ.get("UMI_DDP_LAUNCH", "graph")        # "graph": see below; "eager": overlapped all-reduce
-    if world > 1 and not a.eager and ddp_launch == "graph" and os.environ.get("UMI_BENCH_GRAPH", "1") != "0":
-        # Data parallel, host-independent variant: forward + loss + backward are replayed from a HIP graph that writes the
-        # gradients straight into the reducer's flat buckets; the bucket all-reduces (RCCL, eager) and the one-launch
-        # optimizer step follow the replay.  The collectives are then NOT overlapped with the backward pass (124 MB of fp32
-        # gradients: ~1 ms at 8 GPUs); UMI_DDP_LAUNCH=eager selects the overlapped, eagerly issued path instead, which is
-        # faster on a fast host and up to 7 ms/step slower on a slow one (measured on this pool at N=1).
+    ddp_launch = "eager" if (a.eager or os.environ.get("UMI_BENCH_GRAPH", "1") == "0") else os.environ.get("UMI_DDP_LAUNCH", "auto")
+    eager_step = step
+    if world > 1 and ddp_launch in ("auto", "graph"):
+        # Data parallel has two launch paths:
+        #   eager: every launch issued from Python, bucket all-reduces overlapped with the rest of the backward pass;
+        #   graph: forward + loss + backward replayed from a HIP graph that writes the gradients straight into the reducer's
+        #          flat buckets, then the bucket all-reduces (RCCL, eager) and the one-launch optimizer step.  ~10 host-issued
+        #          launches per step instead of ~350, but the 124 MB of gradients are reduced after the backward pass.
+        # Which one is faster depends on the host (measured on this pool at N=1: eager 24.8 .. 31.7 ms, graph 23.9 .. 25.2 ms),
+        # so "auto" times three steps of each during the warm-up and keeps the faster; every rank takes the same decision
+        # (MAX over ranks of each timing).  The graph is captured FIRST: on ROCm 7.2 an eager step between a graph's warm-up
+        # and its capture crashes hipStreamEndCapture.
         from umi.graphs import GraphedStep
-        reducer.deferred = True
+        trace = os.environ.get("UMI_BENCH_TRACE") == "1"
 
         def fwd_bwd(xx, yy):
             logits = model(xx)
@@ -235,14 +240,25 @@ def main():
             opt.zero_grad()
             loss.backward()
             return loss
+
+        def timed(fn, n):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+
+        t_graph = float("inf")
+        graph_step = None
         try:
-            graphed = GraphedStep(fwd_bwd, [x, labels], warmup=1)
+            reducer.deferred = True
+            gs = GraphedStep(fwd_bwd, [x, labels], warmup=1)
 
-            trace = os.environ.get("UMI_BENCH_TRACE") == "1"
-
-            def step():
+            def graph_step():
                 t0 = time.perf_counter()
-                loss = graphed(x, labels)
+                loss = gs(x, labels)
                 t1 = time.perf_counter()
                 reducer.flush()
                 t2 = time.perf_counter()
@@ -251,13 +267,30 @@ def main():
                     print(f"[trace] replay {1e3 * (t1 - t0):.1f} ms  flush {1e3 * (t2 - t1):.1f} ms  "
                           f"opt {1e3 * (time.perf_counter() - t2):.1f} ms (host times)", file=sys.stderr, flush=True)
                 return loss
-            for _ in range(a.warmup):
-                step()
+            for _ in range(max(1, a.warmup)):
+                graph_step()                                   # also brings RCCL up
+            t_graph = timed(graph_step, 3)
         except Exception as e:
-            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
-            graphed = None
-            reducer.deferred = False
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            graph_step = None
             torch.cuda.synchronize()
+        reducer.deferred = False
+        t_eager = float("inf")
+        if ddp_launch == "auto" or graph_step is None:
+            for _ in range(max(1, a.warmup)):
+                eager_step()
+            t_eager = timed(eager_step, 3)
+        tt = torch.tensor([min(t_graph, 1e9), min(t_eager, 1e9)], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_graph, t_eager = tt.tolist()
+        if rank == 0:
+            print(f"[bench] launch paths at N={world}: graph {1e3 * t_graph:.2f} ms/step, eager {1e3 * t_eager:.2f} ms/step",
+                  file=sys.stderr)
+        if graph_step is not None and t_graph <= t_eager:
+            reducer.deferred = True
+            step, graphed = graph_step, gs
+        else:
+            step, graphed = eager_step, None
     if world == 1 and not a.eager and os.environ.get("UMI_BENCH_GRAPH", "1") != "0":
         from umi.graphs import GraphedStep
 
@@ -275,7 +308,7 @@ def main():
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
             graphed = None
             torch.cuda.synchronize()
-    if graphed is None:
+    if graphed is None and not (world > 1 and ddp_launch in ("auto", "graph")):
         for _ in range(a.warmup):
             step()
     launch = "eager" if graphed is None else ("hipgraph" if world == 1 else "hipgraph(fwd+bwd) + eager all-reduce + optimizer")

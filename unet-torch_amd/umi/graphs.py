@@ -19,7 +19,7 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, step_fn, example_inputs, warmup=3):
+    def __init__(self, step_fn, example_inputs, warmup=3, capture_error_mode=None):
         """step_fn(*static_inputs) -> tensor or tuple of tensors (e.g. the loss); it must run the whole step, including
         `optimizer.zero_grad(set_to_none=True)`, `backward()` and `optimizer.step()`."""
         if not all(t.is_cuda for t in example_inputs):
@@ -38,8 +38,15 @@ class GraphedStep:
                 step_fn(*self.static_inputs)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if capture_error_mode is None:
+            # with a process group alive, its watchdog thread polls HIP events of earlier collectives; in the default
+            # "global" mode such a call from ANOTHER thread invalidates the capture.  Nothing captured here comes from
+            # that thread, so only this thread's calls are checked.
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            capture_error_mode = "thread_local" if multi else "global"
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             self.static_outputs = step_fn(*self.static_inputs)
 
     def __call__(self, *inputs):
