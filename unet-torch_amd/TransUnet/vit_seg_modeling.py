@@ -14,7 +14,6 @@ Not supported: `vis=True` (attention maps are never materialised), the non-hybri
 """
 import copy
 import logging
-import math
 
 import numpy as np
 import torch
@@ -24,7 +23,6 @@ from torch.nn.modules.utils import _pair
 
 from Model import _TapeFunction, _resolve_dtype
 from umi import graph as G
-from umi import ops
 from umi.graph_tu import TUTape
 
 from . import vit_seg_configs as configs

@@ -5,7 +5,6 @@ HIP kernel in libunetmi.so.  Tensors are NHWC views `[N, H, W, C]` whose last di
 contiguous and whose pixel stride (`stride(2)`) may exceed C (channel slice of a
 concat buffer).
 """
-import math
 
 import torch
 
@@ -152,7 +151,7 @@ class PackCache:
 
     def __init__(self):
         self.ents = {}
-        self._tables = {}          # tuple(entry keys) -> (device table, host table, total_blocks, n)
+        self._tables = {}          # tuple(entry keys) -> (device address of the descriptor table, total_blocks, n)
 
     _CAP = 1 << 18                     # bytes of descriptor-table space (a U-Net's table is 3 KB)
 
