@@ -104,7 +104,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const int ty0 = (rem / tiles_x) * TH, tx0 = (rem % tiles_x) * 32;
     const int c0 = cb * BN;
     const int cvalid = Co - c0 < BN ? Co - c0 : BN;   // output channels of this tile that exist (Co % 8 == 0, e.g. Co = 16)
-    const int q = tid & 1;                         // which 8-channel half of the 16-channel chunk this thread stages
+    // Staging-thread -> LDS-row mapping.  ds_write_b128 is serviced in groups of 8 consecutive lanes against 32 banks: with
+    // the 48-byte rows, 8 lanes covering 4 rows x both halves collide 2-way on half the banks (measured: 25-30 % of the
+    // kernel's LDS-array cycles were SQ_LDS_BANK_CONFLICT, profiles/r01_conv_fwd_lds_mfma.json); 8 lanes covering 8
+    // consecutive rows of ONE half fall on 32 distinct banks.  Global coalescing is unchanged: a wave still touches the same
+    // 32 rows x 32 bytes.
+    const int q = (tid >> 3) & 1;                  // which 8-channel half of the 16-channel chunk this thread stages
+    const int srow = ((tid >> 4) << 3) | (tid & 7);   // this thread's row among the 128 staged per pass
 
     // ---- per-thread staging plan (fixed across chunks) ------------------------------------------
     // Loads go through buffer descriptors: an out-of-range voffset returns zeros, so zero padding and partial
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     unsigned hoff[C::KPH];                         // byte offset inside image n, or OOB (zero padding / no piece)
 #pragma unroll
     for (int k = 0; k < C::KPH; ++k) {
-        int hp = (tid >> 1) + 128 * k;
+        int hp = srow + 128 * k;
         int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         bool inimg = (hp < C::HALO_PIX) && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -122,17 +128,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(x + (long)n * H * W * ldx), 0, (int)((long)H * W * ldx * 2), 0x00020000);
-    const int hl_base = (tid >> 1) * ROWB + q * 16;           // + k * 128 * ROWB
+    const int hl_base = srow * ROWB + q * 16;                 // + k * 128 * ROWB
     // weight piece k: row rc = (tid>>1) + 128k of the [9*BN] rows -> tap = k*(128/BN) + (tid>>1)/BN
     constexpr int TSTEP = 128 / BN;
-    const int tap0 = (tid >> 1) / BN, wcol = (tid >> 1) % BN;
+    const int tap0 = srow / BN, wcol = srow % BN;
     const bool wok = wcol < cvalid;                // weight rows past Co read as zeros
     const int Ci8 = Ci >> 3;
     const unsigned wbase = (unsigned)(((tap0 * Ci8 + q) * Co + wcol) * 16);
     const unsigned wstep = (unsigned)(TSTEP * Ci8 * Co * 16);   // bytes per k step
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(wp8 + (long)c0 * 8), 0, (int)((long)9 * Ci * Co * 2 - (long)c0 * 16), 0x00020000);
-    const int wl_base = C::HB + (tid >> 1) * ROWB + q * 16;    // + k * 128 * ROWB
+    const int wl_base = C::HB + srow * ROWB + q * 16;          // + k * 128 * ROWB
 
     floatx16 acc[2][4];
 #pragma unroll
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #ifndef UMI_EXP_NO_STAGE
 #pragma unroll
         for (int k = 0; k < C::KPH; ++k)
-            if ((tid >> 1) + 128 * k < C::HALO_PIX) *reinterpret_cast<half8*>(smem + hl_base + k * 128 * ROWB) = hraw[k];
+            if (srow + 128 * k < C::HALO_PIX) *reinterpret_cast<half8*>(smem + hl_base + k * 128 * ROWB) = hraw[k];
 #pragma unroll
         for (int k = 0; k < C::KPW; ++k)
             if (tap0 + k * TSTEP < 9) *reinterpret_cast<half8*>(smem + wl_base + k * 128 * ROWB) = wraw[k];
