@@ -295,6 +295,8 @@ def main():
         from umi.graphs import GraphedStep
 
         def step_xy(xx, yy):
+            if os.environ.get("UMI_BENCH_INJECT_CAPTURE_FAILURE") == "1" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected failure during capture (fallback rehearsal)")
             logits = model(xx)
             loss = L.calc_loss(logits, yy, loss_type="dice_bce_mc")
             opt.zero_grad()
@@ -308,6 +310,9 @@ def main():
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
             graphed = None
             torch.cuda.synchronize()
+            torch.cuda.empty_cache()                     # drop the failed capture's private pool
+            for _ in range(3):                           # the side-stream warm-up cached its blocks for another stream
+                step()
     if graphed is None and not (world > 1 and ddp_launch in ("auto", "graph")):
         for _ in range(a.warmup):
             step()
