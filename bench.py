@@ -341,7 +341,7 @@ def main():
         value = a.batch * world * a.steps / dt
         gf = unet_fwd_gflop_per_image(a.cin, a.ncls, a.features, a.size, a.size)
         out = {
-            "metric": "images/sec training step, 4-level U-Net 1ch->2cls 512x512",
+            "metric": "images/sec training step, 4-level U-Net 1ch\u21922cls 512\u00d7512, at 1/2/4/8 MI355X",   # BASELINE.json's metric, verbatim
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else "f32", "data": "synthetic",
