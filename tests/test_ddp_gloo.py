@@ -45,8 +45,20 @@ def _worker(rank, world, port, q):
     red.finish()
     sink = [red.buffer_for(p).clone() for p in m.parameters()]
     red.reset()
+    # deferred mode (graph-replayed backward): filling the buckets launches nothing, flush() reduces them afterwards and
+    # points .grad at the slots
+    red.deferred = True
+    for p, g in reversed(list(zip(m.parameters(), local))):
+        red.buffer_for(p).copy_(g * red.grad_scale)
+        red.mark_ready(p)
+    red.finish()
+    untouched = all(torch.equal(red.buffer_for(p), g * red.grad_scale) for p, g in zip(m.parameters(), local))
+    red.flush()
+    deferred = [p.grad.clone() for p in m.parameters()]
+    aliased = all(p.grad.data_ptr() == red.buffer_for(p).data_ptr() for p in m.parameters())
+    red.deferred = False
     q.put((rank, [t.numpy() for t in local], [t.numpy() for t in avg], [t.numpy() for t in sink],
-           [p.detach().numpy() for p in m.parameters()]))
+           [p.detach().numpy() for p in m.parameters()], [t.numpy() for t in deferred], untouched and aliased))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,8 +75,11 @@ def test_grad_reducer_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, l0, a0, s0, w0), (_, l1, a1, s1, w1) = res
+    (_, l0, a0, s0, w0, d0, ok0), (_, l1, a1, s1, w1, d1, ok1) = res
+    assert ok0 and ok1                       # deferred mode: nothing reduced before flush(); .grad aliases the bucket slots
     for i in range(len(l0)):
+        np.testing.assert_allclose(d0[i], (l0[i] + l1[i]) / 2, rtol=1e-6, atol=1e-8)
+        np.testing.assert_array_equal(d0[i], d1[i])
         np.testing.assert_array_equal(w0[i], w1[i])                     # broadcast made replicas identical
         want = (l0[i] + l1[i]) / 2
         np.testing.assert_allclose(a0[i], want, rtol=1e-6, atol=1e-8)
