@@ -13,7 +13,9 @@ Rules that make the capture valid (the class enforces what it can):
   * random streams must advance on the device: TransUNet's dropout kernels take their per-step offset from a device
     counter (`umi_dropout(seed_dev=...)`), so every replay draws fresh masks;
   * the optimizer's hyper-parameters are frozen at capture time (rebuild the GraphedStep to change the learning rate);
-  * single process only: the RCCL gradient all-reduce of `umi.ddp.GradReducer` is not captured.
+  * collectives are never captured: data parallel runs capture forward + backward only, with `GradReducer.deferred = True`
+    (the tape fills the gradient buckets and launches nothing), and call `reducer.flush()` + `optimizer.step()` after each
+    replay (bench.py, UMI_DDP_LAUNCH=graph); with a process group alive the capture uses the thread_local error mode.
 """
 import torch
 
