@@ -138,7 +138,8 @@ class TUTape(Tape):
         out = self.alloc(N, H, W, Co, device=a.raw.device)
         w4 = weight.detach().float().reshape(Co, Ci, 1, 1)
         b32 = bias.detach().float() if bias is not None else None
-        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(w4, self.dtype, k8=bool(lay)), b32, out, 1, 1, 1, 0)
+        # (kernel-layout copies from the model's PackCache when `weight` is a parameter: MLP / out-projection / patch embedding)
+        ops.conv_fwd(a.raw, a.tx, lambda lay: self._pack("conv_fwd", weight, w4, bool(lay)), b32, out, 1, 1, 1, 0)
         o = Act(out, None)
         if self.record:
             def bwd():
@@ -153,7 +154,7 @@ class TUTape(Tape):
                     self._set_pgrad(bias, gb)
                 if _wants_grad(a):
                     dx = self.alloc(N, H, W, Ci, device=out.device)
-                    ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(w4, self.dtype, k8=bool(lay)), None, dx, 1, 1, 1, 0)
+                    ops.conv_fwd(o.grad, None, lambda lay: self._pack("conv_dgrad", weight, w4, bool(lay)), None, dx, 1, 1, 1, 0)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o

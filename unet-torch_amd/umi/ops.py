@@ -120,6 +120,8 @@ def pack_convT_dgrad(w: torch.Tensor, dtype, k8=False):
 
 def _pack_args(kind, shape):
     """(T, K, N, st, sk, sn, flip_t) of the four weight packings above."""
+    if len(shape) == 2:                              # nn.Linear weight [Co, Ci] = a 1x1 convolution
+        shape = (shape[0], shape[1], 1, 1)
     if kind == "conv_fwd":
         Co, Ci, R, S = shape
         return R * S, Ci, Co, 1, R * S, Ci * R * S, 0
