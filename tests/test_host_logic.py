@@ -56,6 +56,16 @@ def test_trainer_reproduces_reference_run(golden_dir, tmp_path):
     assert pick(log) == pick(ref_log)
     for k, v in m.state_dict().items():
         _sig_close(sig(v.float()), g["final." + k], rtol=5e-4)
+    # checkpoint compatibility (reference Trainer.py:759-765,808: bare state_dicts): what the Trainer wrote loads, with the
+    # safe loader and strict key matching, into the reference-shaped oracle model and into the product model
+    import Model
+    for name in ("best.pt", "last_epoch.pt"):
+        sd = torch.load(tmp_path / "models" / name, weights_only=True)
+        assert list(sd.keys()) == list(m.state_dict().keys())
+        ref_unet.RefUNet(1, 2, 8, False).load_state_dict(sd, strict=True)
+        prod = Model.UNet(1, 2, 8, False)
+        prod.load_state_dict(sd, strict=True)
+        assert all(torch.equal(a, b) for a, b in zip(prod.state_dict().values(), sd.values()))
 
 
 def test_trainer_rejects_out_of_scope(tmp_path):
