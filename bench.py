@@ -239,6 +239,8 @@ def main():
             loss = L.calc_loss(logits, yy, loss_type="dice_bce_mc")
             opt.zero_grad()
             loss.backward()
+            if os.environ.get("UMI_BENCH_INJECT_CAPTURE_FAILURE_RANK") == str(rank) and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected capture failure on this rank (fallback rehearsal)")
             return loss
 
         def timed(fn, n):
@@ -252,10 +254,25 @@ def main():
 
         t_graph = float("inf")
         graph_step = None
+        gs = None
         try:
             reducer.deferred = True
-            gs = GraphedStep(fwd_bwd, [x, labels], warmup=1)
-
+            gs = GraphedStep(fwd_bwd, [x, labels], warmup=1)       # deferred reducer: no collective in here
+        except Exception as e:
+            print(f"[bench] rank {rank}: HIP-graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+            gs = None
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        # the ranks must agree on the path BEFORE the next collective: a rank that fell back alone would pair its eager
+        # all-reduces with the others' flushes and hang at the first barrier
+        ok = torch.tensor([1.0 if gs is not None else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0.0:
+            if gs is not None and rank == 0:
+                print("[bench] another rank could not capture; all ranks use eager launches", file=sys.stderr)
+            gs = None
+            torch.cuda.empty_cache()
+        if gs is not None:
             def graph_step():
                 t0 = time.perf_counter()
                 loss = gs(x, labels)
@@ -268,13 +285,10 @@ def main():
                           f"opt {1e3 * (time.perf_counter() - t2):.1f} ms (host times)", file=sys.stderr, flush=True)
                 return loss
             for _ in range(max(1, a.warmup)):
-                graph_step()                                   # also brings RCCL up
+                graph_step()
             t_graph = timed(graph_step, 3)
-        except Exception as e:
-            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
-            graph_step = None
-            torch.cuda.synchronize()
         reducer.deferred = False
+        reducer.reset()                                  # a failed capture leaves buckets marked but never flushed
         t_eager = float("inf")
         if ddp_launch == "auto" or graph_step is None:
             for _ in range(max(1, a.warmup)):
