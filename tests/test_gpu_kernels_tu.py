@@ -334,6 +334,49 @@ def test_pointwise_mfma_partial_tiles_and_bn_stats_pass(case):
     torch.testing.assert_close(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("case", [(2, 9, 13, 32, 1), (1, 40, 40, 256, 1), (2, 7, 5, 64, 3), (3, 33, 31, 128, 8)])
+def test_narrow_pointwise_fp16_out_with_stat_epilogue(case):
+    """1x1 conv with <= 8 output channels and an fp16 output that feeds a BatchNorm (the attention gate's psi branch, reference
+    Model.py:283-287): the narrow-output kernel with its statistics epilogue against torch and against the generic kernel."""
+    lib, ops, T = _gpu()
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, Ci, generator=g).half()
+    w = torch.randn(Co, Ci, 1, 1, generator=g) * (2.0 / Ci) ** 0.5
+    t = torch.empty(Ci, 4)
+    t[:, 0] = 0.0
+    t[:, 1] = 0.5 + torch.rand(Ci, generator=g)
+    t[:, 2] = 0.2 * torch.randn(Ci, generator=g)
+    t[:, 3] = 0.0
+    a = torch.maximum(x.float() * t[:, 1] + t[:, 2], t[:, 3])
+    ref = torch.nn.functional.conv2d(a.permute(0, 3, 1, 2), w.half().float()).permute(0, 2, 3, 1)
+    xd, wd, td = x.to(DEV), w.to(DEV), t.to(DEV).contiguous()
+    res = {}
+    for name, flags in (("narrow", 0), ("generic", lib.CONV_FORCE_GENERIC)):
+        y = torch.empty(N, H, W, Co, device=DEV, dtype=torch.float16)
+        lay, rows = ops.conv_plan(xd, y, 1, 1, 1, 0, flags)
+        assert lay == 0
+        part = ops.conv_fwd(xd, td, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), None, y, 1, 1, 1, 0,
+                            want_stats=True, flags=flags)
+        assert part.numel() == rows * 2 * Co
+        res[name] = (y.float().cpu(), part.view(-1, 2, Co).sum(0).cpu())
+    assert res["narrow"][1].shape == res["generic"][1].shape
+    scale = ref.abs().max().item()
+    for name in res:
+        y, sums = res[name]
+        assert (y - ref).abs().max().item() < 2e-3 * scale, name
+        yf = y.reshape(-1, Co)                                  # statistics are those of the ROUNDED stored values
+        torch.testing.assert_close(sums[0], yf.sum(0), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(sums[1], (yf * yf).sum(0), rtol=1e-4, atol=1e-3)
+    # without statistics the same kernel runs (fp16 out), and the fp32-out instance still serves the logits
+    y0 = torch.empty(N, H, W, Co, device=DEV, dtype=torch.float16)
+    ops.conv_fwd(xd, td, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), None, y0, 1, 1, 1, 0)
+    assert torch.equal(y0.float().cpu(), res["narrow"][0])
+    y32 = torch.empty(N, H, W, Co, device=DEV, dtype=torch.float32)
+    ops.conv_fwd(xd, td, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), None, y32, 1, 1, 1, 0)
+    assert (y32.cpu() - ref).abs().max().item() < 2e-4 * scale
+
+
 @pytest.mark.parametrize("shape", [(2 * 9 * 13, 128, 32), (400, 32, 128), (70, 96, 40), (256, 16, 16)])
 def test_wgrad1x1_mfma_partial_channel_tiles(shape):
     """Weight gradient of a plain 1x1 conv on the MFMA kernel with channel counts that are only multiples of 8 (attention

@@ -37,8 +37,9 @@ size_t umi_stem_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
 int umi_stem_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
                    long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s);
 bool umi_head_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int in_dtype, int out_dtype, int flags);
-int umi_head_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy, long P,
-                 int Ci, int Co, hipStream_t s);
+int umi_head_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy, float* part,
+                 long P, int Ci, int Co, int out_dtype, hipStream_t s);
+int umi_head_stat_rows(long P, int Ci);
 bool umi_smallk_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldy, int in_dtype, int out_dtype, int flags,
                        const void* tx, const float* bias);
 int umi_smallk_fwd(const void* x, int ldx, const void* wp, void* y, int ldy, long P, int Ci, int Co, hipStream_t s);
@@ -104,9 +105,12 @@ extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int
     if (layout) *layout = (mfma || mfma1) ? 1 : 0;
     const bool stem = !mfma && !mfma1 && !dgs &&
                       umi_stem_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, has_bias ? &one : nullptr);
+    const bool head = !mfma && !mfma1 && !dgs && !stem && out_dtype == UMI_F16 &&
+                      umi_head_fwd_ok(Ci, Co, R, S, stride, pad, ldx, in_dtype, out_dtype, flags);
     if (stat_rows)
         *stat_rows = mfma ? umi_conv3x3_mfma_stat_rows(N, H, W, Co)
-                          : (stem ? umi_stem_stat_rows(N, H, W) : umi_cdiv((long)N * Ho * Wo, 64));
+                          : (stem ? umi_stem_stat_rows(N, H, W)
+                                  : (head ? umi_head_stat_rows((long)N * H * W, Ci) : umi_cdiv((long)N * Ho * Wo, 64)));
     return UMI_OK;
 }
 
@@ -219,8 +223,8 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
     }
     if (umi_stem_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, bias))
         return umi_stem_fwd(x, ldx, tx, wp, y, ldy, stat_part, N, H, W, Ci, Co, (hipStream_t)stream);
-    if (!stat_part && umi_head_fwd_ok(Ci, Co, R, S, stride, pad, ldx, in_dtype, out_dtype, flags))
-        return umi_head_fwd(x, ldx, tx, wp, bias, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
+    if ((!stat_part || out_dtype == UMI_F16) && umi_head_fwd_ok(Ci, Co, R, S, stride, pad, ldx, in_dtype, out_dtype, flags))
+        return umi_head_fwd(x, ldx, tx, wp, bias, y, ldy, stat_part, (long)N * H * W, Ci, Co, out_dtype, (hipStream_t)stream);
     if (!stat_part && umi_smallk_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias))
         return umi_smallk_fwd(x, ldx, wp, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
     if (!stat_part && umi_root_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias))

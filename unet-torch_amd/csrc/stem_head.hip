@@ -207,12 +207,15 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const half_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// head forward: logits[p][k] = bias[k] + sum_c tx(x[p][c]) * w[c][k]   (fp32 out, NHWC, ldy = ncls or more)
-template <int NC>
+// head forward: y[p][k] = bias[k] + sum_c tx(x[p][c]) * w[c][k]   (NHWC, ldy = ncls or more)
+// TO = float: the segmentation logits.  TO = half_t: a narrow pointwise conv inside the network (the attention gate's 1-channel
+// psi branch, reference Model.py:283-287); STATS then also emits the BatchNorm partial sums part[block][2][NC] of the ROUNDED
+// outputs, like every other conv epilogue of the library.
+template <int NC, typename TO, bool STATS>
 __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const half_t* __restrict__ x, int ldx,
                                                           const float4* __restrict__ tx, const half_t* __restrict__ wp,
-                                                          const float* __restrict__ bias, float* __restrict__ y, int ldy,
-                                                          long P, int C) {
+                                                          const float* __restrict__ bias, TO* __restrict__ y, int ldy,
+                                                          float* __restrict__ part, long P, int C) {
     const int G = C >> 3;                                   // lanes per pixel (power of two <= 64)
     const long gt = (long)blockIdx.x * 256 + threadIdx.x;
     const int cg = (int)(gt % G);
@@ -225,6 +228,9 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const half_t* __restri
 #pragma unroll
         for (int k = 0; k < NC; ++k) w[j][k] = (float)wp[(cg * 8 + j) * NC + k];
     }
+    float ssum[NC], ssq[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) ssum[k] = ssq[k] = 0.f;
     const long Pr = ((P + stride_p - 1) / stride_p) * stride_p;      // keep whole pixel groups in the shuffle
     for (long p = gt / G; p < Pr; p += stride_p) {
         float acc[NC];
@@ -244,7 +250,37 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const half_t* __restri
             for (int k = 0; k < NC; ++k) acc[k] += __shfl_xor(acc[k], o);
         if (cg == 0 && p < P) {
 #pragma unroll
-            for (int k = 0; k < NC; ++k) y[p * ldy + k] = acc[k] + (bias ? bias[k] : 0.f);
+            for (int k = 0; k < NC; ++k) {
+                const TO o = (TO)(acc[k] + (bias ? bias[k] : 0.f));
+                y[p * ldy + k] = o;
+                if (STATS) {
+                    const float vr = (float)o;
+                    ssum[k] += vr;
+                    ssq[k] = fmaf(vr, vr, ssq[k]);
+                }
+            }
+        }
+    }
+    if (STATS) {
+        __shared__ float red[4][2][NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            for (int o = 32; o > 0; o >>= 1) {
+                ssum[k] += __shfl_xor(ssum[k], o);
+                ssq[k] += __shfl_xor(ssq[k], o);
+            }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                red[threadIdx.x >> 6][0][k] = ssum[k];
+                red[threadIdx.x >> 6][1][k] = ssq[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * NC) {
+            const int which = threadIdx.x / NC, k = threadIdx.x - which * NC;
+            part[((long)blockIdx.x * 2 + which) * NC + k] =
+                (red[0][which][k] + red[1][which][k]) + (red[2][which][k] + red[3][which][k]);
         }
     }
 }
@@ -284,12 +320,12 @@ template <int NC>
 __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const half_t* __restrict__ x, int ldx,
                                                             const float4* __restrict__ tx,
                                                             const half_t* __restrict__ dl, int lddl,
-                                                            float* __restrict__ part, long P, int C) {
+                                                            float* __restrict__ part, long P, int C, int ppb) {
     __shared__ float red[256][9];
     const int tid = threadIdx.x;
     const int G = C >> 3, PL = 256 / G;
     const int cg = tid % G, pl = tid / G;
-    const long p0 = (long)blockIdx.x * WG_PPB;
+    const long p0 = (long)blockIdx.x * ppb;
     float4 t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) t[j] = tx ? tx[cg * 8 + j] : make_float4(0.f, 1.f, 0.f, -INFINITY);
@@ -298,7 +334,7 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const half_t* __rest
     for (int k = 0; k < NC; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
-    for (long p = p0 + pl; p < p0 + WG_PPB && p < P; p += PL) {
+    for (long p = p0 + pl; p < p0 + ppb && p < P; p += PL) {
         half8 v = *reinterpret_cast<const half8*>(x + p * ldx + cg * 8);
         float a[8];
 #pragma unroll
@@ -377,20 +413,29 @@ int umi_stem_wgrad(const void* x, int ldx, const void* txa, const void* dy, int 
     return UMI_OK;
 }
 
-// head forward: fp16 in, fp32 out, 1x1, Co <= 8 (weights in generic [1][Ci][Co] fp16 packing)
+// head forward: fp16 in, 1x1, Co <= 8 (weights in generic [1][Ci][Co] fp16 packing); fp32 out (logits) or fp16 out (+ statistics)
 bool umi_head_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int in_dtype, int out_dtype, int flags) {
     if (flags & (UMI_CONV_UPSAMPLE2 | UMI_CONV_FORCE_GENERIC)) return false;
-    return in_dtype == UMI_F16 && out_dtype == UMI_F32 && R == 1 && S == 1 && stride == 1 && pad == 0 && Co >= 1 &&
-           Co <= 8 && groups_ok(Ci) && ldx % 8 == 0;
+    return in_dtype == UMI_F16 && (out_dtype == UMI_F32 || out_dtype == UMI_F16) && R == 1 && S == 1 && stride == 1 &&
+           pad == 0 && Co >= 1 && Co <= 8 && groups_ok(Ci) && ldx % 8 == 0;
 }
-int umi_head_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy, long P,
-                 int Ci, int Co, hipStream_t s) {
+int umi_head_stat_rows(long P, int Ci) { return grid_for(P * (Ci / 8)); }
+int umi_head_fwd(const void* x, int ldx, const void* tx, const void* wp, const float* bias, void* y, int ldy, float* part,
+                 long P, int Ci, int Co, int out_dtype, hipStream_t s) {
     if (!al16(x)) return UMI_ERR_BADARG;
+    if (part && out_dtype != UMI_F16) return UMI_ERR_UNSUPPORTED;
     int grid = grid_for(P * (Ci / 8));
-#define GO(NC) hipLaunchKernelGGL(head1x1_fwd_kernel<NC>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)tx, (const half_t*)wp, bias, (float*)y, ldy, P, Ci)
+#define GO_(NC, TO, ST) hipLaunchKernelGGL((head1x1_fwd_kernel<NC, TO, ST>), dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)tx, (const half_t*)wp, bias, (TO*)y, ldy, part, P, Ci)
+#define GO(NC)                                                          \
+    do {                                                                \
+        if (out_dtype == UMI_F32) GO_(NC, float, false);                \
+        else if (part) GO_(NC, half_t, true);                           \
+        else GO_(NC, half_t, false);                                    \
+    } while (0)
     switch (Co) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
                   case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
 #undef GO
+#undef GO_
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }
@@ -418,15 +463,25 @@ bool umi_head_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int ld
     return dtype == UMI_F16 && !txb && R == 1 && S == 1 && stride == 1 && pad == 0 && Co >= 1 && Co <= 8 && groups_ok(Ci) &&
            Ci <= 256 && ldx % 8 == 0;
 }
+// pixels per workgroup of the head weight gradient: ~2048 workgroups where the tensor allows it (a fixed 4096 left the 64x64
+// maps of the attention gates with 16 workgroups: 249 us for 34 MB), whole multiples of 256 pixels
+static int head_wgrad_ppb(long P) {
+    long ppb = (P + 2047) / 2048;
+    ppb = ((ppb + 255) / 256) * 256;
+    if (ppb > WG_PPB) ppb = WG_PPB;
+    return (int)ppb;
+}
 size_t umi_head_wgrad_ws_bytes(long P, int Ci, int Co) {
-    return (size_t)((P + WG_PPB - 1) / WG_PPB) * Ci * Co * sizeof(float);
+    const int ppb = head_wgrad_ppb(P);
+    return (size_t)((P + ppb - 1) / ppb) * Ci * Co * sizeof(float);
 }
 int umi_head_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
                    long s_t, float out_scale, long P, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s) {
     if (ws_bytes < umi_head_wgrad_ws_bytes(P, Ci, Co)) return UMI_ERR_WORKSPACE;
     if (!al16(x)) return UMI_ERR_BADARG;
-    int blocks = (int)((P + WG_PPB - 1) / WG_PPB);
-#define GO(NC) hipLaunchKernelGGL(head1x1_wgrad_kernel<NC>, dim3(blocks), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, P, Ci)
+    const int ppb = head_wgrad_ppb(P);
+    int blocks = (int)((P + ppb - 1) / ppb);
+#define GO(NC) hipLaunchKernelGGL(head1x1_wgrad_kernel<NC>, dim3(blocks), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, P, Ci, ppb)
     switch (Co) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
                   case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
 #undef GO

@@ -150,12 +150,14 @@ class Tape:
         wf = weight.detach().float()
         # the pointwise matrix-core kernel has no statistics epilogue: a 1x1 conv that feeds a BatchNorm (attention gates) runs
         # it without statistics and takes them in a separate HBM-bound pass over its (small: C_hidden channels) output; where
-        # neither applies (odd channel counts, the 1-channel psi conv) the generic kernel produces both
+        # neither applies (odd channel counts) the generic kernel produces both
         part, flags, two_pass = None, 0, False
         if self.training and (R, S) == (1, 1):
             two_pass = (self.dtype == torch.float16 and Co % 8 == 0 and
                         ops.conv_plan(a.raw, out, R, S, stride, pad, 0, False)[0] == 1)
-            flags = 0 if two_pass else L.CONV_FORCE_GENERIC
+            # Co <= 8 (the gate's 1-channel psi conv): the narrow-output kernel, which has the statistics epilogue itself
+            narrow = self.dtype == torch.float16 and Co <= 8
+            flags = 0 if (two_pass or narrow) else L.CONV_FORCE_GENERIC
         res = ops.conv_fwd(a.raw, a.tx, lambda lay: self._pack("conv_fwd", weight, wf, bool(lay)), None, out,
                            R, S, stride, pad, want_stats=self.training and not two_pass, flags=flags)
         part = ops.bn_stats(out) if two_pass else res
