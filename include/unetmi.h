@@ -39,8 +39,12 @@ enum { UMI_OK = 0, UMI_ERR_BADARG = -1, UMI_ERR_UNSUPPORTED = -2, UMI_ERR_WORKSP
 /* umi_conv_fwd flags */
 enum { UMI_CONV_UPSAMPLE2 = 1,   /* ConvTranspose2d(k=2,s=2): tap t=(dy,dx) scatters to (2h+dy+off_h, 2w+dx+off_w) */
        UMI_CONV_FORCE_GENERIC = 2, /* never take the MFMA fast path (used by tests to cross-check it) */
-       UMI_CONV_DGRAD_STRIDED = 4  /* data gradient of a stride>1 conv: x = dy [N,H,W,Ci:=Co_fwd], y = dx [N,Ho,Wo,Co:=Ci_fwd]
-                                      with (R,S,stride,pad) of the FORWARD conv; weights packed [R*S][Co_fwd][Ci_fwd] unflipped */ };
+       UMI_CONV_DGRAD_STRIDED = 4, /* data gradient of a stride>1 conv: x = dy [N,H,W,Ci:=Co_fwd], y = dx [N,Ho,Wo,Co:=Ci_fwd]
+                                      with (R,S,stride,pad) of the FORWARD conv; weights packed [R*S][Co_fwd][Ci_fwd] unflipped */
+       UMI_CONV_ACCUMULATE = 8     /* y += conv(...) instead of y = conv(...): the second gradient contribution of a tensor with two
+                                      consumers (attention gate, reference Model.py:268-289: g and x each feed two branches).  Only
+                                      the pointwise / tap-gather MFMA kernel implements it: umi_conv_fwd_plan and umi_conv_fwd return
+                                      UMI_ERR_UNSUPPORTED for any other problem, nothing is written */ };
 
 int umi_version(void);
 const char* umi_arch(void);          /* "gfx950" */

@@ -377,6 +377,54 @@ def test_narrow_pointwise_fp16_out_with_stat_epilogue(case):
     assert (y32.cpu() - ref).abs().max().item() < 2e-4 * scale
 
 
+def test_conv_accumulate_flag_adds_into_the_output():
+    """UMI_CONV_ACCUMULATE (second gradient contribution of a tensor with two consumers): the pointwise and the tap-gather
+    (ConvTranspose data gradient) MFMA kernels add their result to the stored fp16 tensor, bit-identically to computing into a
+    fresh tensor and adding; other problems are refused by the plan, and nothing is written."""
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(77)
+    # (a) plain 1x1 (the gate's W_x data gradient), output is a channel slice of a wider tensor
+    N, H, W, Ci, Co = 2, 9, 13, 32, 64
+    x = torch.randn(N, H, W, Ci, generator=g).half().to(DEV)
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) * 0.2).to(DEV)
+    pk = lambda l: ops.pack_conv_fwd(w, torch.float16, k8=bool(l))
+    fresh = torch.empty(N, H, W, Co, device=DEV, dtype=torch.float16)
+    ops.conv_fwd(x, None, pk, None, fresh, 1, 1, 1, 0)
+    wide = torch.randn(N, H, W, Co + 16, generator=g).half().to(DEV)
+    tgt = wide[..., 8:8 + Co]
+    want = tgt + fresh
+    keep = wide.clone()
+    assert ops.conv_accumulate_ok(x, tgt, 1, 1, 1, 0)
+    ops.conv_fwd(x, None, pk, None, tgt, 1, 1, 1, 0, flags=lib.CONV_ACCUMULATE)
+    assert torch.equal(tgt, want)
+    assert torch.equal(wide[..., :8], keep[..., :8]) and torch.equal(wide[..., 8 + Co:], keep[..., 8 + Co:])
+    # (b) ConvTranspose2d(2,2) data gradient = stride-2 2x2 tap gather
+    Cin, Cout, h, wd = 128, 64, 6, 5
+    gy = torch.randn(N, 2 * h, 2 * wd, Cout, generator=g).half().to(DEV)
+    wt = (torch.randn(Cin, Cout, 2, 2, generator=g) * 0.1).to(DEV)
+    pkt = lambda l: ops.pack_convT_dgrad(wt, torch.float16, k8=bool(l))
+    fresh = torch.empty(N, h, wd, Cin, device=DEV, dtype=torch.float16)
+    ops.conv_fwd(gy, None, pkt, None, fresh, 2, 2, 2, 0)
+    ref = torch.nn.functional.conv2d(gy.float().permute(0, 3, 1, 2), wt.half().float(), stride=2).permute(0, 2, 3, 1)
+    assert (fresh.float() - ref).abs().max().item() < 4e-3 * ref.abs().max().item()
+    tgt = torch.randn(N, h, wd, Cin, generator=g).half().to(DEV)
+    want = tgt + fresh
+    assert ops.conv_accumulate_ok(gy, tgt, 2, 2, 2, 0)
+    ops.conv_fwd(gy, None, pkt, None, tgt, 2, 2, 2, 0, flags=lib.CONV_ACCUMULATE)
+    assert torch.equal(tgt, want)
+    # (c) refused elsewhere: 3x3, fp32, forced generic
+    x3 = torch.randn(1, 8, 8, 64, generator=g).half().to(DEV)
+    y3 = torch.zeros(1, 8, 8, 64, device=DEV, dtype=torch.float16)
+    assert not ops.conv_accumulate_ok(x3, y3, 3, 3, 1, 1)
+    assert not ops.conv_accumulate_ok(x3, y3, 1, 1, 1, 0, flags=lib.CONV_FORCE_GENERIC)
+    assert not ops.conv_accumulate_ok(x3.float(), y3.float(), 1, 1, 1, 0)
+    w3 = (torch.randn(64, 64, 3, 3, generator=g) * 0.1).to(DEV)
+    with pytest.raises(RuntimeError):
+        ops.conv_fwd(x3, None, lambda l: ops.pack_conv_fwd(w3, torch.float16, k8=bool(l)), None, y3, 3, 3, 1, 1,
+                     flags=lib.CONV_ACCUMULATE)
+    assert float(y3.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape", [(2 * 9 * 13, 128, 32), (400, 32, 128), (70, 96, 40), (256, 16, 16)])
 def test_wgrad1x1_mfma_partial_channel_tiles(shape):
     """Weight gradient of a plain 1x1 conv on the MFMA kernel with channel counts that are only multiples of 8 (attention

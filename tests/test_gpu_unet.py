@@ -504,6 +504,38 @@ def test_predict_mask_matches_reference_eval_argmax(golden_dir):
     assert torch.equal(mask, mask2) and vers == {k: e.ver for k, e in m._umi_pack_cache.ents.items()}
 
 
+def test_attention_dgrad_accumulate_is_bit_identical(monkeypatch):
+    """Tensors with two consumers (attention gate: g and x) get their second gradient contribution added by the data-gradient
+    kernel itself (UMI_CONV_ACCUMULATE); with the knob off the tape computes into a fresh tensor and adds.  Same bits."""
+    _need_gpu()
+    import Model
+    import loss as L
+    from umi import ops
+    L.CLASS_NUMBER = 2
+    torch.manual_seed(5)
+    m = Model.UNet_attention(1, 2, 64, False, compute_dtype="fp16").to(DEV).train()
+    x = torch.randn(2, 1, 64, 64, device=DEV)
+    lab = torch.randint(0, 2, (2, 64, 64), device=DEV).float()
+    calls = []
+    real = ops.conv_fwd
+
+    def spy(*a, **k):
+        calls.append(k.get("flags", 0))
+        return real(*a, **k)
+    monkeypatch.setattr(ops, "conv_fwd", spy)
+    grads = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("UMI_NO_DGRAD_ACCUMULATE", knob)
+        calls.clear()
+        m.zero_grad(set_to_none=True)
+        L.calc_loss(m(x), lab, loss_type="dice_bce_mc").backward()
+        n_acc = sum(1 for f in calls if f & 8)
+        assert n_acc == (8 if knob == "0" else 0), (knob, n_acc)      # 4 gates x (ConvT data gradient, W_x data gradient)
+        grads[knob] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for k in grads["0"]:
+        assert torch.equal(grads["0"][k], grads["1"][k]), k
+
+
 def _is_dead_bias(k):
     """Conv biases directly in front of a BatchNorm (attention gate W_q / W_x / psi): their gradient vanishes identically;
     the reference leaves ~1e-10 of rounding noise there, the HIP path writes exact zeros."""

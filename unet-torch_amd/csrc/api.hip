@@ -102,6 +102,7 @@ extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int
     const bool mfma = !dgs && umi_conv3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, in_dtype, out_dtype,
                                                   flags, has_bias ? &one : nullptr);
     const bool mfma1 = !mfma && umi_conv1x1_mfma_ok(Ci, Co, R, S, stride, pad, ldx, ldy, in_dtype, out_dtype, flags);
+    if ((flags & UMI_CONV_ACCUMULATE) && !mfma1) return UMI_ERR_UNSUPPORTED;
     if (layout) *layout = (mfma || mfma1) ? 1 : 0;
     const bool stem = !mfma && !mfma1 && !dgs &&
                       umi_stem_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, has_bias ? &one : nullptr);
@@ -189,6 +190,12 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
     if (!x || !wp || !y || N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
         Ho <= 0 || Wo <= 0 || ldx < Ci || ldy < Co || out_H <= 0 || out_W <= 0)
         return UMI_ERR_BADARG;
+    if (flags & UMI_CONV_ACCUMULATE) {
+        // only the pointwise / tap-gather MFMA kernel adds into y, and where it is eligible it is the path taken below (the 3x3
+        // kernel's stride-1 pad-1 problems are never eligible for it)
+        if (stat_part || !umi_conv1x1_mfma_ok(Ci, Co, R, S, stride, pad, ldx, ldy, in_dtype, out_dtype, flags))
+            return UMI_ERR_UNSUPPORTED;
+    }
     if (flags & UMI_CONV_DGRAD_STRIDED) {
         // x = dy of a strided conv (H x W), output grid = the conv's input image (Ho x Wo)
         if (flags & UMI_CONV_UPSAMPLE2) return UMI_ERR_BADARG;

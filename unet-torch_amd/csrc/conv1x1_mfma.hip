@@ -34,6 +34,7 @@ struct Geo {                  // geometry of the (optionally strided) source / d
     int Hs, Ws, soy, sox;     // source tensor dims (+ window offset) ; GATHER: source pixel = (s*y+ty-pad+soy, s*x+tx-pad+sox)
     int Hd, Wd, doy, dox;     // destination dims (+ offset)          ; for OUT_UPS dest pixel = (2y+dy+doy, 2x+dx+dox)
     int S, stride, pad, frac; // GATHER: taps per row, stride, padding; frac = data gradient of a strided conv
+    int accum;                // UMI_CONV_ACCUMULATE: y += result (fp16 add of the stored and the new value)
 };
 
 template <int P, int BN, bool GATHER, bool OUT_UPS, bool HAS_TX>
@@ -256,7 +257,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
                 if (yy < 0 || yy >= geo.Hd || xx < 0 || xx >= geo.Wd) continue;
             }
             uint4 v = *reinterpret_cast<const uint4*>(smem + p * ERS + j * 16);
-            *reinterpret_cast<uint4*>(y + ((long)((long)pi.x * geo.Hd + yy) * geo.Wd + xx) * ldy + co) = v;
+            half_t* dst = y + ((long)((long)pi.x * geo.Hd + yy) * geo.Wd + xx) * ldy + co;
+            if (geo.accum) {
+                // a second gradient contribution lands on the tensor the first one wrote: same rounding as adding two
+                // stored fp16 tensors
+                const half8 o = *reinterpret_cast<const half8*>(dst);
+                v = __builtin_bit_cast(uint4, (half8)(o + __builtin_bit_cast(half8, v)));
+            }
+            *reinterpret_cast<uint4*>(dst) = v;
         }
     }
 }
@@ -330,6 +338,7 @@ int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, co
     const long want = 400;                                  // ~0.8 of the 512 resident workgroup slots
     const long b_256_128 = ((M + 255) / 256) * (Ntot / 128), b_128_128 = ((M + 127) / 128) * (Ntot / 128);
     const long b_256_64 = ((M + 255) / 256) * (Ntot / 64);
+    geo.accum = (flags & UMI_CONV_ACCUMULATE) ? 1 : 0;
 #define GO(P_, BN_) return launch<P_, BN_>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s)
     if (bn128 && b_256_128 >= want) GO(256, 128);
     if (b_256_64 >= want) GO(256, 64);

@@ -109,6 +109,15 @@ class Tape:
         else:
             act.grad.add_(g)
 
+    def _accumulate_target(self, act: Act, src, R, S, stride, pad):
+        """The tensor a conv-shaped data gradient of `act` can be ADDED into by the kernel itself, or None.  An activation
+        with two consumers (attention gate: g and x, reference Model.py:268-289) receives its second contribution this way
+        instead of through a fresh tensor and an add pass; same rounding (stored fp16 + fp16)."""
+        if (act.parts is not None or not act.needs_grad or act.grad is None or act.grad.dtype != torch.float16
+                or os.environ.get("UMI_NO_DGRAD_ACCUMULATE") == "1"):
+            return None
+        return act.grad if ops.conv_accumulate_ok(src, act.grad, R, S, stride, pad) else None
+
     def finish_forward(self):
         """Host-side bookkeeping batched at the end of the forward pass (one launch instead of one per layer)."""
         if self._nbt:
@@ -210,6 +219,12 @@ class Tape:
                 if _wants_grad(a):
                     if stride != 1:
                         raise NotImplementedError("dgrad for strided conv_bn")
+                    tgt = self._accumulate_target(a, o.grad, R, S, 1, R - 1 - pad)
+                    if tgt is not None:
+                        ops.conv_fwd(o.grad, None, lambda lay: self._pack("conv_dgrad", weight, wf, bool(lay)), None, tgt,
+                                     R, S, 1, R - 1 - pad, flags=L.CONV_ACCUMULATE)
+                        a.gives += 1
+                        return
                     dx = self.alloc(N, H, W, Ci, device=out.device)
                     part = None
                     if (input_exclusive and _fuse_bnred() and a.grad is None and a.parts is None and a.bn_rstd is not None
@@ -323,6 +338,12 @@ class Tape:
                 ops.conv_wgrad(g, None, a.raw, a.tx, gw, Cout * 4, 4, 1, inv, 2, 2, 2, 0)
                 self._set_pgrad(weight, gw)
                 if _wants_grad(a):
+                    tgt = self._accumulate_target(a, g, 2, 2, 2, 0)
+                    if tgt is not None:
+                        ops.conv_fwd(g, None, lambda lay: self._pack("convT_dgrad", weight, wf, bool(lay)), None, tgt,
+                                     2, 2, 2, 0, flags=L.CONV_ACCUMULATE)
+                        a.gives += 1
+                        return
                     dx = self.alloc(N, h, w, Cin, device=dest.device)
                     ops.conv_fwd(g, None, lambda lay: self._pack("convT_dgrad", weight, wf, bool(lay)), None, dx,
                                  2, 2, 2, 0)

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_
 from . import build as _build
 
 UMI_F32, UMI_F16 = 0, 1
-CONV_UPSAMPLE2, CONV_FORCE_GENERIC, CONV_DGRAD_STRIDED = 1, 2, 4
+CONV_UPSAMPLE2, CONV_FORCE_GENERIC, CONV_DGRAD_STRIDED, CONV_ACCUMULATE = 1, 2, 4, 8
 
 _ERR = {-1: "UMI_ERR_BADARG", -2: "UMI_ERR_UNSUPPORTED", -3: "UMI_ERR_WORKSPACE"}
 

@@ -281,6 +281,17 @@ def conv_plan(x, y, R, S, stride, pad, flags=0, has_bias=False):
     return lay.value, rows.value
 
 
+def conv_accumulate_ok(x, y, R, S, stride, pad, flags=0):
+    """True when libunetmi can ADD this conv's result into y (flags | CONV_ACCUMULATE): only its pointwise / tap-gather
+    matrix-core kernel does; the caller otherwise computes into a fresh tensor and adds."""
+    N, H, W, Ci, ldx = _nhwc(x)
+    _, _, _, Co, ldy = _nhwc(y)
+    if (x.data_ptr() | y.data_ptr()) & 15:
+        return False
+    return L.fn("umi_conv_fwd_plan")(N, H, W, Ci, Co, R, S, stride, pad, ldx, ldy, _dt(x), _dt(y),
+                                     flags | L.CONV_ACCUMULATE, 0, None, None) == 0
+
+
 def conv_fwd(x, tx, wp, bias, y, R, S, stride, pad, want_stats=False, flags=0, up_offset=(0, 0)):
     """y <- conv(tx(x), wp) [+ bias]; returns the stats-partials tensor when want_stats.
     `wp` is a packed weight tensor or a callable(layout) -> packed tensor (see conv_plan)."""
