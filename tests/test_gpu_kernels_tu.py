@@ -377,6 +377,43 @@ def test_narrow_pointwise_fp16_out_with_stat_epilogue(case):
     assert (y32.cpu() - ref).abs().max().item() < 2e-4 * scale
 
 
+@pytest.mark.parametrize("C,dt", [(32, torch.float16), (256, torch.float16), (24, torch.float16), (12, torch.float16),
+                                  (20, torch.float32)])
+def test_add2_relu_fwd_bwd_vector_and_scalar_paths(C, dt):
+    """E = relu(tx_a(a) + tx_b(b)) of the attention gate (reference Model.py:302) and its backward, against torch: 16-B lanes
+    when C/8 is a power of two (32, 256), the scalar kernels otherwise (24, 12, fp32); strided (channel-slice) operands."""
+    lib, ops, T = _gpu()
+    N, H, W = 2, 7, 9
+    g = torch.Generator().manual_seed(C)
+    wide = lambda: torch.randn(N, H, W, C + 8, generator=g).to(dt).to(DEV)
+    A, B = wide(), wide()
+    a, b = A[..., :C], B[..., 8:]
+    def mk():
+        t = torch.empty(C, 4)
+        t[:, 0] = 0.0
+        t[:, 1] = 0.5 + torch.rand(C, generator=g)
+        t[:, 2] = 0.3 * torch.randn(C, generator=g)
+        t[:, 3] = float("-inf")
+        return t
+    ta, tb = mk(), mk()
+    y = torch.empty(N, H, W, C, device=DEV, dtype=dt)
+    ops.add2_relu(a, ta.to(DEV), b, tb.to(DEV), y)
+    ref = torch.relu(a.float().cpu() * ta[:, 1] + ta[:, 2] + b.float().cpu() * tb[:, 1] + tb[:, 2])
+    tol = 2e-3 if dt == torch.float16 else 1e-6
+    assert (y.float().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    y2 = torch.empty_like(y)
+    ops.add2_relu(a, None, b, tb.to(DEV), y2)                       # one side consumed as stored
+    ref2 = torch.relu(a.float().cpu() + b.float().cpu() * tb[:, 1] + tb[:, 2])
+    assert (y2.float().cpu() - ref2).abs().max().item() <= tol * max(1.0, ref2.abs().max().item())
+    dy = torch.randn(N, H, W, C, generator=g).to(dt).to(DEV)
+    DA = torch.full((N, H, W, C + 8), 3.0, device=DEV, dtype=dt)
+    da, db = DA[..., :C], torch.empty(N, H, W, C, device=DEV, dtype=dt)
+    ops.add2_relu_bwd(dy, y, da, db)
+    want = torch.where(y > 0, dy, torch.zeros_like(dy))
+    assert torch.equal(da, want) and torch.equal(db, want)
+    assert float(DA[..., C:].min()) == 3.0                            # nothing written past the slice
+
+
 def test_conv_accumulate_flag_adds_into_the_output():
     """UMI_CONV_ACCUMULATE (second gradient contribution of a tensor with two consumers): the pointwise and the tap-gather
     (ConvTranspose data gradient) MFMA kernels add their result to the stored fp16 tensor, bit-identically to computing into a

@@ -152,6 +152,52 @@ __global__ __launch_bounds__(256) void gate_bwd_v8(const half_t* __restrict__ dy
     }
 }
 
+// add2_relu, 16 B per lane (same arithmetic as the scalar kernels: fp32 transform, one rounding of the result)
+__global__ __launch_bounds__(256) void add2_relu_fwd_v8(const half_t* __restrict__ a, int lda, const float4* __restrict__ txa,
+                                                        const half_t* __restrict__ b, int ldb, const float4* __restrict__ txb,
+                                                        half_t* __restrict__ y, int ldy, long M, int G) {
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);
+    const long stride = ((long)gridDim.x * 256) / G;
+    const float4 ident = make_float4(0.f, 1.f, 0.f, -INFINITY);
+    float4 ta[8], tb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ta[j] = txa ? txa[cg * 8 + j] : ident;
+        tb[j] = txb ? txb[cg * 8 + j] : ident;
+    }
+    for (long m = gt / G; m < M; m += stride) {
+        const half8g va = *reinterpret_cast<const half8g*>(a + m * lda + cg * 8);
+        const half8g vb = *reinterpret_cast<const half8g*>(b + m * ldb + cg * 8);
+        half8g o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float fa = (float)va[j], fb = (float)vb[j];
+            if (txa) fa = txf(fa, ta[j]);
+            if (txb) fb = txf(fb, tb[j]);
+            o[j] = (half_t)fmaxf(fa + fb, 0.f);
+        }
+        *reinterpret_cast<half8g*>(y + m * ldy + cg * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void add2_relu_bwd_v8(const half_t* __restrict__ dy, int lddy, const half_t* __restrict__ y,
+                                                        int ldy, half_t* __restrict__ da, int ldda, half_t* __restrict__ db,
+                                                        int lddb, long M, int G) {
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);
+    const long stride = ((long)gridDim.x * 256) / G;
+    for (long m = gt / G; m < M; m += stride) {
+        const half8g g = *reinterpret_cast<const half8g*>(dy + m * lddy + cg * 8);
+        const half8g v = *reinterpret_cast<const half8g*>(y + m * ldy + cg * 8);
+        half8g o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (float)v[j] > 0.f ? g[j] : (half_t)0.f;
+        *reinterpret_cast<half8g*>(da + m * ldda + cg * 8) = o;
+        *reinterpret_cast<half8g*>(db + m * lddb + cg * 8) = o;
+    }
+}
+
 inline bool gate_vec_ok(int C, int l0, int l1, int l2, const void* a, const void* b, const void* c) {
     const int G = C / 8;
     if (C % 8 || G > 64 || (G & (G - 1)) || l0 % 8 || l1 % 8 || l2 % 8) return false;
@@ -169,6 +215,13 @@ extern "C" int umi_add2_relu_fwd(const void* a, int lda, const void* txa, const 
                                  int ldy, long M, int C, int dtype, umi_stream_t stream) {
     if (!a || !b || !y || M <= 0 || C <= 0 || lda < C || ldb < C || ldy < C) return UMI_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F16 && gate_vec_ok(C, lda, ldb, ldy, a, b, y)) {
+        const int G = C / 8;
+        hipLaunchKernelGGL(add2_relu_fwd_v8, dim3(ew_grid(M * G, 256 * 4)), dim3(256), 0, s, (const half_t*)a, lda,
+                           (const float4*)txa, (const half_t*)b, ldb, (const float4*)txb, (half_t*)y, ldy, M, G);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     const int grid = ew_grid(M * C, 256 * 4);
     if (dtype == UMI_F16)
         hipLaunchKernelGGL(add2_relu_fwd_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)a, lda, (const float4*)txa,
@@ -185,6 +238,13 @@ extern "C" int umi_add2_relu_bwd(const void* dy, int lddy, const void* y, int ld
                                  long M, int C, int dtype, umi_stream_t stream) {
     if (!dy || !y || !da || !db || M <= 0 || C <= 0 || lddy < C || ldy < C || ldda < C || lddb < C) return UMI_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == UMI_F16 && gate_vec_ok(C, lddy, ldy, ldda, dy, y, da) && lddb % 8 == 0 && ((uintptr_t)db & 15) == 0) {
+        const int G = C / 8;
+        hipLaunchKernelGGL(add2_relu_bwd_v8, dim3(ew_grid(M * G, 256 * 4)), dim3(256), 0, s, (const half_t*)dy, lddy,
+                           (const half_t*)y, ldy, (half_t*)da, ldda, (half_t*)db, lddb, M, G);
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     const int grid = ew_grid(M * C, 256 * 4);
     if (dtype == UMI_F16)
         hipLaunchKernelGGL(add2_relu_bwd_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)y,
