@@ -336,7 +336,8 @@ def _build_attention(t, q, x, ab, dest):
     if (2 * h, 2 * w) != tuple(x.shape[1:3]):
         raise ValueError(f"attention gate: upsampled query {2 * h}x{2 * w} != skip {x.shape[1]}x{x.shape[2]} "
                          "(the reference's Q1 + X1 fails the same way)")
-    qu = t.conv_transpose2x2(q, ab.up.weight, ab.up.bias, t.alloc(N, 2 * h, 2 * w, Cq, device=q.raw.device))
+    qu = t.conv_transpose2x2(q, ab.up.weight, ab.up.bias, t.alloc(N, 2 * h, 2 * w, Cq, device=q.raw.device),
+                             bias_cancelled=True)       # up -> W_q (1x1) -> BatchNorm: see Tape.conv_transpose2x2
     q1 = t.conv_bn(qu, ab.W_q[0].weight, ab.W_q[1], pad=0, relu=False, bias=ab.W_q[0].bias)
     x1 = t.conv_bn(x, ab.W_x[0].weight, ab.W_x[1], pad=0, relu=False, bias=ab.W_x[0].bias)
     e = t.add_relu(q1, x1)

@@ -302,9 +302,12 @@ class Tape:
             self.steps.append(bwd)
         return o
 
-    def conv_transpose2x2(self, a: Act, weight, bias, dest, out_hw=None):
+    def conv_transpose2x2(self, a: Act, weight, bias, dest, out_hw=None, bias_cancelled=False):
         """ConvTranspose2d(k=2,s=2)+bias written into `dest` (a channel slice of a concat
-        buffer, spatial size = the skip's), centred like F.pad in reference Model.py:69-73."""
+        buffer, spatial size = the skip's), centred like F.pad in reference Model.py:69-73.
+        bias_cancelled: the output feeds only an unpadded 1x1 conv followed by a training-mode BatchNorm (the attention gate's
+        `up` -> `W_q`): the bias is a per-channel constant that the BatchNorm subtracts again, its gradient vanishes identically
+        and is written as zeros instead of a column sum over the upsampled gradient."""
         Cin, Cout = weight.shape[:2]
         N, h, w, Ca = a.shape
         assert Ca == Cin
@@ -331,7 +334,10 @@ class Tape:
                     g = g[:, oy:oy + 2 * h, ox:ox + 2 * w, :].contiguous()
                 if bias is not None:
                     gb = self._new_pgrad(bias)
-                    ops.colsum(g, gb, inv)
+                    if bias_cancelled and self.training and not (dY or dX):
+                        gb.zero_()
+                    else:
+                        ops.colsum(g, gb, inv)
                     self._set_pgrad(bias, gb)
                 gw = self._new_pgrad(weight)
                 # dW[ci][co][t] = sum_p act(a)[p][ci] * g[2p+t][co]: a wgrad with the roles of x and dy swapped
