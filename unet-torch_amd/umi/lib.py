@@ -37,6 +37,7 @@ _lib = _load()
 SIGNATURES = {
     "umi_version": (c_int, []),
     "umi_arch": (c_char_p, []),
+    "umi_tune_conv3x3_impl": (c_int, [c_int]),
     "umi_pack_kn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_int, c_int,
                             c_int, c_void_p]),
     "umi_pack_kn8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_int, c_int,
