@@ -420,7 +420,7 @@ int umi_conv3x3_mfma2(const void* x, int ldx, const void* tx, const void* wp8, v
 static int g_impl = [] { const char* e = getenv("UMI_CONV3X3_IMPL"); return e ? atoi(e) : 1; }();
 extern "C" int umi_tune_conv3x3_impl(int impl) {
     const int old = g_impl;
-    if (impl >= 1 && impl <= 3) g_impl = impl;
+    if (impl >= 1 && impl <= 4) g_impl = impl;
     return old;
 }
 

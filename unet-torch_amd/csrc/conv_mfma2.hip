@@ -20,6 +20,19 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifdef UMI2_STAMP
+// diagnostic build only (tools/build_variant.py -DUMI2_STAMP): per-wave cycle sums of the main loop's two waits
+__device__ unsigned long long umi2_stamp_buf[2 * 4096 * 8];
+#define UMI2_T(var)                                                                       \
+    unsigned long long var;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0)
+extern "C" int umi_debug_read_stamps2(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(umi2_stamp_buf), sizeof(umi2_stamp_buf));
+}
+#endif
+
 namespace {
 
 constexpr int TH = 16, BN = 64;
@@ -66,7 +79,7 @@ __device__ __forceinline__ u32x4 umi_make_rsrc(const void* p, unsigned bytes) {
     return r;
 }
 
-template <bool HAS_TX, int EPI, int STAGE_AT>
+template <bool HAS_TX, int EPI, int STAGE_AT, bool PAIR>
 __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     half_t* __restrict__ y, int ldy, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x,
@@ -78,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef UMI2_STAMP
+    UMI2_T(t_k0);
+#endif
 
     int wid = blockIdx.x;
     if (xcd_chunk > 0 && wid < 8 * xcd_chunk) wid = (wid & 7) * xcd_chunk + (wid >> 3);
@@ -129,13 +145,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
 
 #endif
 
-    half8 hraw[KPH];
+    half8 hraw2[2][KPH];          // [set][piece]; without PAIR only set 0 is used
+#define hraw hraw2[hs_]
 #ifdef UMI2_NO_HALO
-#define UMI_ISSUE_H(c_) do {} while (0)
-#define UMI_STAGE_H(buf_, tb_) do {} while (0)
+#define UMI_ISSUE_H(c_, set_) do {} while (0)
+#define UMI_STAGE_H(buf_, tb_, set_) do {} while (0)
 #else
-#define UMI_ISSUE_H(c_)                                                                                            \
+#define UMI_ISSUE_H(c_, set_)                                                                                      \
     do {                                                                                                           \
+        constexpr int hs_ = (set_);                                                                                \
         _Pragma("unroll") for (int k = 0; k < KPH; ++k)                                                            \
             hraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[k], (c_) * 32, 0)); \
     } while (0)
@@ -150,8 +168,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
 #else
 #define UMI2_HW(p_, v_) *reinterpret_cast<half8*>(p_) = v_
 #endif
-#define UMI_STAGE_H(buf_, tb_)                                                                                     \
+#define UMI_STAGE_H(buf_, tb_, set_)                                                                               \
     do {                                                                                                           \
+        constexpr int hs_ = (set_);                                                                                \
         if (UMI2_TXON) {                                                                                           \
             float4 t[8];                                                                                           \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) t[j] = txbuf[(tb_) * 16 + j * 2 + q];                    \
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
     int txrow = lane & 15;
 
     // ---- prologue: chunk 0 into buffer 0, chunk 1's loads in flight ------------------------------
-    UMI_ISSUE_H(0);
+    UMI_ISSUE_H(0, 0);
     UMI_DMA_W(0, 0);
     if (HAS_TX) {
         // every wave writes the same 16 rows (4 lanes per row): no divergent region in the loop below
@@ -192,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
         if (nchunks > 2) txr = tx[2 * 16 + (lane & 15)];
         __syncthreads();
     }
-    UMI_STAGE_H(0, 0);
-    if (nchunks > 1) UMI_ISSUE_H(1);
+    UMI_STAGE_H(0, 0, 0);
+    if (nchunks > 1) UMI_ISSUE_H(1, PAIR ? 1 : 0);
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(0) : "memory");
 
     // timing-only ablation switches (tools/build_variant.py; results are wrong by construction, never in the shipped library)
@@ -212,16 +231,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
 #endif
 #ifdef UMI2_NO_BARRIER
 #define UMI2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#elif defined(UMI2_STAMP)
+#define UMI2_BARRIER() do { UMI2_T(tb0_); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); UMI2_T(tb1_); st_bar += tb1_ - tb0_; } while (0)
 #else
 #define UMI2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+#ifdef UMI2_STAMP
+    unsigned long long tseg_;
+#define UMI2_SEG_BEGIN() do { UMI2_T(ts_); tseg_ = ts_; } while (0)
+#define UMI2_SEG(acc_) do { UMI2_T(ts_); acc_ += ts_ - tseg_; tseg_ = ts_; } while (0)
+    unsigned long long st_vm = 0, st_bar = 0, seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0, seg4 = 0;
+#define UMI2_WAIT_VM() do { UMI2_T(tv0_); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); UMI2_T(tv1_); st_vm += tv1_ - tv0_; } while (0)
+    UMI2_T(t_loop0);
+#else
+#define UMI2_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define UMI2_SEG_BEGIN() do {} while (0)
+#define UMI2_SEG(acc_) do {} while (0)
 #endif
 
     // One chunk: MFMAs of chunk c_ from buffers b_, with (N1: chunk c_+1 exists) the DMA of its weights at the top and the
     // staging of its halo after tap column STAGE_AT, and (N2: chunk c_+2 exists) the loads of that chunk's halo behind it.
-#define UMI_BODY(c_, b_, N1, N2)                                                                                   \
+#define UMI_BODY(c_, b_, N1, N2, PAR, NT)                                                                                \
     do {                                                                                                           \
+        UMI2_SEG_BEGIN();                                                                                          \
         if (N1) UMI_DMA_W((c_) + 1, (b_) ^ 1);                                                                     \
         __builtin_amdgcn_s_setprio(1);                                                                             \
+        UMI2_SEG(seg0);                                                                                            \
         _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                                         \
             half8 bf[6];                                                                                           \
             _Pragma("unroll") for (int rr = 0; rr < 6; ++rr)                                                       \
@@ -234,21 +269,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
                     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                               \
                         UMI2_MFMA(acc[mt][nt], af[mt], bf[nt + dy]);                                               \
             }                                                                                                      \
+            if (dx == 0) UMI2_SEG(seg1); else if (dx == 1) UMI2_SEG(seg2); else UMI2_SEG(seg3);                    \
             if (N1 && dx == STAGE_AT) {                                                                            \
                 /* everything this wave has in flight is due now: the halo of chunk c+1, its transform rows, and the DMA of \
                    chunk c+1's weights (which must have landed before the barrier below).  The kernel does not rely on       \
                    hipcc's own vmcnt bookkeeping for the DMA (it cannot see it). */                                         \
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-                UMI_STAGE_H((b_) ^ 1, (b_) ^ 1);                                                                   \
+                UMI2_WAIT_VM();                                                                                    \
+                UMI_STAGE_H((b_) ^ 1, (b_) ^ 1, PAIR ? ((PAR) ^ 1) : 0);                                           \
                 /* the next loads depend on these registers, so no pass can hoist them above the wait */           \
                 _Pragma("unroll") for (int k = 0; k < KPH; ++k) asm volatile("" : "+v"(hoff[k]));                  \
-                if (HAS_TX && N2) {                                                                                \
+                if (HAS_TX && NT) {                                                                                \
                     txbuf[(b_) * 16 + txl] = txr;            /* rows of chunk c+2; this buffer's rows (chunk c) were last read during c-1 */ \
                     int cn = (c_) + 3 < nchunks ? (c_) + 3 : nchunks - 1;                                          \
                     asm volatile("" : "+v"(txrow));                                                                \
                     txr = tx[cn * 16 + txrow];                                                                     \
                 }                                                                                                  \
-                if (N2) UMI_ISSUE_H((c_) + 2);                                                                     \
+                if (!PAIR) { if (N2) UMI_ISSUE_H((c_) + 2, 0); }                                                   \
+                else if ((PAR) == 0 && N2) {        /* both register sets are free: two chunks' loads back to back, the second \
+                                                       touches the lines the first one just brought into L1 */          \
+                    _Pragma("unroll") for (int k = 0; k < KPH; ++k) {        /* piece-major: the two loads of a line are adjacent */ \
+                        hraw2[0][k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[k], ((c_) + 2) * 32, 0)); \
+                        hraw2[1][k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[k], ((c_) + 3) * 32, 0)); \
+                    }                                                                                              \
+                }                                                                                                  \
+                UMI2_SEG(seg4);                                                                                    \
             }                                                                                                      \
         }                                                                                                          \
         __builtin_amdgcn_s_setprio(0);                                                                             \
@@ -256,21 +300,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
         UMI2_BARRIER();                                                                                            \
     } while (0)
 
-    int c = 0;
-    for (; c + 2 < nchunks; ++c) {
-        const int b = c & 1;
-        UMI_BODY(c, b, true, true);
-    }
-    if (c + 1 < nchunks) {
-        const int b = c & 1;
-        UMI_BODY(c, b, true, false);
-        ++c;
-    }
-    {
-        const int b = c & 1;
-        UMI_BODY(c, b, false, false);
+    if (!PAIR) {
+        int c = 0;
+        for (; c + 2 < nchunks; ++c) {
+            const int b = c & 1;
+            UMI_BODY(c, b, true, true, 0, true);
+        }
+        if (c + 1 < nchunks) {
+            const int b = c & 1;
+            UMI_BODY(c, b, true, false, 0, false);
+            ++c;
+        }
+        {
+            const int b = c & 1;
+            UMI_BODY(c, b, false, false, 0, false);
+        }
+    } else {
+        // nchunks is even (the launcher guarantees it): chunk c lives in LDS buffers / register set c & 1
+        int c = 0;
+        for (; c + 2 < nchunks; c += 2) {
+            UMI_BODY(c, 0, true, true, 0, true);
+            UMI_BODY(c + 1, 1, true, false, 1, true);
+        }
+        UMI_BODY(c, 0, true, false, 0, false);
+        UMI_BODY(c + 1, 1, false, false, 1, false);
     }
 
+#ifdef UMI2_STAMP
+    UMI2_T(t_loop1);
+#endif
     // ---- epilogue (as conv_mfma.hip): acc -> fp16 LDS tile [pixel][BN] -> 16-B stores + per-channel sums -------
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -353,12 +411,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(
             if (cc < cvalid) part[((long)pt * 2 + which) * Co + c0 + cc] = a;
         }
     }
+#ifdef UMI2_STAMP
+    UMI2_T(t_k1);
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = umi2_stamp_buf + (blockIdx.x * 4 + wave) * 8;
+        o[0] = t_loop0 - t_k0; o[1] = t_loop1 - t_loop0; o[2] = t_k1 - t_loop1; o[3] = st_vm; o[4] = st_bar; o[5] = nchunks;
+        unsigned long long* o2 = umi2_stamp_buf + 4096 * 8 + (blockIdx.x * 4 + wave) * 8;
+        o2[0] = seg0; o2[1] = seg1; o2[2] = seg2; o2[3] = seg3; o2[4] = seg4;
+    }
+#endif
 }
 
 #undef UMI_BODY
+#undef hraw
 #undef UMI2_LDS
 #undef UMI2_MFMA
 #undef UMI2_BARRIER
+#undef UMI2_WAIT_VM
+#undef UMI2_SEG
+#undef UMI2_SEG_BEGIN
 #undef UMI_DMA_W
 #undef UMI_ISSUE_H
 #undef UMI_STAGE_H
@@ -378,11 +449,16 @@ int umi_conv3x3_mfma2(const void* x, int ldx, const void* tx, const void* wp8, v
     static const bool xcd_off = [] { const char* e = getenv("UMI_CONV_NO_XCD_ORDER"); return e && e[0] == '1'; }();
     const int xcd_chunk = (n_co > 1 && !xcd_off) ? (int)(nblk / 8) : 0;
     const BnRed2 bn{(const half_t*)bn_y, bn_ld, (const float4*)bn_tx, bn_rstd};
-#define GO(HT, EP, SA)                                                                                           \
-    hipLaunchKernelGGL((conv3x3_v2_kernel<HT, EP, SA>), grid, block, 0, s, (const half_t*)x, ldx,                \
+#define GO(HT, EP, SA, PR)                                                                                       \
+    hipLaunchKernelGGL((conv3x3_v2_kernel<HT, EP, SA, PR>), grid, block, 0, s, (const half_t*)x, ldx,            \
                        (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
                        tiles_y, n_co, xcd_chunk, bn)
-#define GO2(HT, EP) do { if (variant == 1) GO(HT, EP, 1); else GO(HT, EP, 0); } while (0)
+#define GO2(HT, EP)                                                                                              \
+    do {                                                                                                         \
+        if (variant == 2 && (Ci & 31) == 0) GO(HT, EP, 1, true);                                                 \
+        else if (variant == 1) GO(HT, EP, 1, false);                                                             \
+        else GO(HT, EP, 0, false);                                                                               \
+    } while (0)
     if (bn_y) { if (tx) GO2(true, 2); else GO2(false, 2); }
     else if (tx) { if (part) GO2(true, 1); else GO2(true, 0); }
     else    { if (part) GO2(false, 1); else GO2(false, 0); }
