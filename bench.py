@@ -124,7 +124,8 @@ def cpu_baseline(cin, ncls, f, H, W, budget_s=25.0):
             cores = max(1, min(cores, int(int(q) / int(per))))
     except (OSError, ValueError):
         pass
-    cores = min(cores, int(os.environ.get("UMI_CPU_BASELINE_THREADS", "16")))   # a one-GPU box's CPU share
+    # every host core this process may use (affinity mask and cgroup quota honoured); UMI_CPU_BASELINE_THREADS caps it
+    cores = min(cores, int(os.environ.get("UMI_CPU_BASELINE_THREADS", str(cores))))
     torch.set_num_threads(cores)
     m = ref_unet.RefUNet(cin, ncls, f, False).train()
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
@@ -149,6 +150,21 @@ def cpu_baseline(cin, ncls, f, H, W, budget_s=25.0):
             "cpu": model}
 
 
+def self_launch(n, argv):
+    """Parent of a multi-GPU run started from a plain shell: one child rank per GPU via torch.distributed.run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] self-launch:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,9 +186,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (and never will); it starts one fresh
+        # rank per GPU under torch.distributed.run, relays their output (rank 0 prints the JSON line) and exits with
+        # their status.  Never exec: the children are ordinary subprocesses.
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     # rehearsal knobs for a one-GPU box (not used by the driver): UMI_DDP_BACKEND=gloo + UMI_BENCH_SAME_GPU=1 run N ranks
     # on device 0 through the same GradReducer / bucket / sink code with gloo carrying the all-reduce
     backend = os.environ.get("UMI_DDP_BACKEND", "nccl")
@@ -219,6 +239,7 @@ def main():
     # trajectory is bit-identical to the eager one, tests/test_gpu_unet.py).  The W warm-up steps run eagerly before the
     # capture, which itself executes nothing.  Data parallel: eager (the RCCL all-reduce is not captured).
     graphed = None
+    path_ms = {}
     ddp_launch = "eager" if (a.eager or os.environ.get("UMI_BENCH_GRAPH", "1") == "0") else os.environ.get("UMI_DDP_LAUNCH", "auto")
     eager_step = step
     if world > 1 and ddp_launch in ("auto", "graph"):
@@ -297,6 +318,8 @@ def main():
         tt = torch.tensor([min(t_graph, 1e9), min(t_eager, 1e9)], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_graph, t_eager = tt.tolist()
+        path_ms = {"hipgraph_fwd_bwd_then_allreduce": None if t_graph >= 1e8 else round(1e3 * t_graph, 3),
+                   "eager_overlapped_allreduce": None if t_eager >= 1e8 else round(1e3 * t_eager, 3)}
         if rank == 0:
             print(f"[bench] launch paths at N={world}: graph {1e3 * t_graph:.2f} ms/step, eager {1e3 * t_eager:.2f} ms/step",
                   file=sys.stderr)
@@ -362,6 +385,9 @@ def main():
             "config": {"workload": f"UNet({a.cin},{a.ncls},{a.features}) train step (fwd + dice_bce_mc + bwd + SGD), "
                                    f"{a.size}x{a.size}, batch {a.batch}/GPU, BASELINE configs[1]",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "launch": launch,
+                       "launch_paths_warmup_ms_per_step": path_ms or None,
+                       "collective": None if world == 1 else {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                                                             "library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend()},
                        "algorithmic_tflops_per_gpu": round(3 * gf * a.batch * a.steps / dt / 1e3, 2)},
             "final_loss": round(final_loss, 5),
         }

@@ -256,6 +256,28 @@ int umi_optim_sgd_multi(const void* descs, int n_desc, int total_blocks, double 
 int umi_optim_adam_multi(const void* descs, int n_desc, int total_blocks, double step_size, double beta1, double beta2,
                          double bc2_sqrt, double eps, double weight_decay, umi_stream_t stream);
 
+/* Graph-safe hyper-parameters (reference Trainer.py:719-726: the poly learning-rate rule rewrites the LR after every step,
+ * torch.optim.Adam advances `step` on the host).  A captured HIP graph freezes kernel ARGUMENTS, so the values that change
+ * from step to step live in a device-resident umi_optim_hyper block per param group instead:
+ *   umi_optim_hyper_pre   before the update: Adam t += 1, step_size_f = lr / (1 - beta1^t), bc2_sqrt_f = sqrt(1 - beta2^t)
+ *                         (formed in double, rounded to fp32 as torch rounds its Python floats); lr_f = (float)lr
+ *   umi_optim_*_multi_dev the same arithmetic as umi_optim_*_multi with lr / step_size / bc2_sqrt read from the block
+ *   umi_optim_hyper_poly  after the update: lr = base_lr * (1 - iter / max_iter)^power; iter += 1  (pre-increment iter, as the
+ *                         reference does)
+ * The host fills the block once (umi_table_upload) and reads it back when it wants param_group['lr'] / state['step']. */
+typedef struct umi_optim_hyper {
+    double lr, base_lr, iter, max_iter, power, adam_t, beta1, beta2;
+    float lr_f, step_size_f, bc2_sqrt_f, pad_;
+    double pad2_[2];
+} umi_optim_hyper;                         /* 96 bytes */
+size_t umi_optim_hyper_bytes(void);
+int umi_optim_hyper_pre(void* hyper, int adam, umi_stream_t stream);
+int umi_optim_hyper_poly(void* hyper, umi_stream_t stream);
+int umi_optim_sgd_multi_dev(const void* descs, int n_desc, int total_blocks, const void* hyper, double momentum,
+                            double dampening, double weight_decay, int nesterov, int first_step, umi_stream_t stream);
+int umi_optim_adam_multi_dev(const void* descs, int n_desc, int total_blocks, const void* hyper, double beta1, double beta2,
+                             double eps, double weight_decay, umi_stream_t stream);
+
 /* umi_pack_kn / umi_pack_kn8 of many weight tensors in one launch (all the convolution weights of a model after an
  * optimizer step).  `descs`: DEVICE array sorted by blk0; an entry owns ceil(T*Kpad*Npad / umi_pack_block_elems()) blocks. */
 typedef struct umi_pack_desc {

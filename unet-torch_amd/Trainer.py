@@ -11,6 +11,11 @@ files `logs.txt`, `models/{epochN,best,last_epoch}.pt`, `total.png`.
 Differences, all host-side: the step body is factored into `train_step` (reused by the
 data-parallel runner, umi/ddp.py) and the running loss is accumulated on the device and read
 back once per epoch instead of a `.item()` sync every step (Trainer.py:727).
+`Trainer(..., graph=True)` (keyword-only, or env UMI_TRAINER_GRAPH=1) replays the whole step from a captured HIP graph
+(umi.graphs.GraphedStep) when the model runs on the MI355X and the optimizer is a `umi.optim` one: the first step of a batch
+shape runs eagerly, the second is captured and replayed, ragged last batches run eagerly.  The poly learning-rate rule
+(:722-725) then advances inside the step from a device-resident block (`optimizer.device_schedule`), because a captured
+kernel argument would freeze it; `param_groups[i]['lr']` is refreshed from the device when it is printed or saved.
 `multi_task_train` (Trainer.py:831-992; model types 'multi_task*' with a plain loss name): two-headed models
 (`Model.UNet_multitask`, `VisionTransformerMultitask`), batches `(inputs, (label1, label2))`, both outputs through
 `F.relu` (:883-884), loss = loss1 + loss2 (:885-890), model selection on the validation LOSS (:926).
@@ -36,7 +41,7 @@ _OTHER = ('CLTR',)
 
 class Trainer():
     def __init__(self, model, model_type, dtype, device, output_save_dir, dataloaders, batch_size, optimizer,
-                 patience, num_epochs, loss_function, accuracy_metric, lr_scheduler=None, start_epoch=1):
+                 patience, num_epochs, loss_function, accuracy_metric, lr_scheduler=None, start_epoch=1, *, graph=None):
         self.model = model
         self.model_type = model_type
         self.dtype = dtype
@@ -63,6 +68,8 @@ class Trainer():
         self.train_loss_list, self.val_loss_list, self.val_score_list = [], [], []
         self.train_loss_list_1, self.train_loss_list_2, self.val_loss_list_1, self.val_loss_list_2 = [], [], [], []
         self.grad_sync = None         # optional callable run between backward and optimizer.step (DDP)
+        self.graph = (os.environ.get("UMI_TRAINER_GRAPH") == "1") if graph is None else bool(graph)
+        self._graphs, self._seen_shapes, self._dev_sched, self._side = {}, set(), False, None
 
         self.save_dir_model = os.path.join(self.output_save_dir, 'models/')
         os.makedirs(self.save_dir_model, exist_ok=True)
@@ -98,9 +105,7 @@ class Trainer():
             out = F.relu(out)
         return out, calc_loss(out, labels, loss_type=self.loss_function)
 
-    def train_step(self, inputs, labels):
-        """One optimisation step (reference Trainer.py:700-726).  Returns the detached loss tensor."""
-        inputs, labels = self._to_device(inputs, labels)
+    def _step_body(self, inputs, labels):
         with torch.set_grad_enabled(True):
             _, loss = self._forward_loss(inputs, labels)
             self.optimizer.zero_grad()
@@ -108,12 +113,55 @@ class Trainer():
             if self.grad_sync is not None:
                 self.grad_sync()
             self.optimizer.step()
+        return loss
+
+    def _graph_capable(self, inputs):
+        return (self.graph and self.grad_sync is None and inputs.is_cuda and hasattr(self.optimizer, "device_schedule"))
+
+    def train_step(self, inputs, labels):
+        """One optimisation step (reference Trainer.py:700-726).  Returns the detached loss tensor."""
+        inputs, labels = self._to_device(inputs, labels)
+        if self._graph_capable(inputs):
+            return self._graphed_train_step(inputs, labels)
+        loss = self._step_body(inputs, labels)
         if self.lr_scheduler:
             lr_ = self.base_lr * (1.0 - self.iter_num / self.max_iterations) ** 0.9
             for group in self.optimizer.param_groups:
                 group['lr'] = lr_
         self.iter_num += 1
         return loss.detach()
+
+    def _graphed_train_step(self, inputs, labels):
+        from umi.graphs import GraphedStep
+        if not self._dev_sched:
+            poly = dict(base_lr=self.base_lr, max_iterations=self.max_iterations, power=0.9, iter_num=self.iter_num)
+            self.optimizer.device_schedule(poly=poly if self.lr_scheduler else None)
+            self._dev_sched, self._side = True, torch.cuda.Stream()
+        flat = [inputs] + (list(labels) if isinstance(labels, (list, tuple)) else [labels])
+        multi = isinstance(labels, (list, tuple))
+        key = tuple(tuple(t.shape) for t in flat)
+
+        def body(x, *ys):
+            loss = self._step_body(x, tuple(ys) if multi else ys[0])
+            return (loss.detach(),) + tuple(l.detach() for l in (self._task_losses if multi else ()))
+
+        gs = self._graphs.get(key)
+        if gs is None and key in self._seen_shapes:
+            gs = self._graphs[key] = GraphedStep(body, flat, warmup=0, optimizers=[self.optimizer])   # 2nd step of a shape: capture, replay
+        if gs is not None:
+            outs = gs(*flat)
+        else:
+            # first step of a batch shape (allocations, weight-pack caches) or a ragged batch: eager, on the side stream (an
+            # eager step on the default stream right before a capture crashes hipStreamEndCapture on ROCm 7.2)
+            self._seen_shapes.add(key)
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                outs = body(*flat)
+            torch.cuda.current_stream().wait_stream(self._side)
+        if multi:
+            self._task_losses = [o.clone() for o in outs[1:]]
+        self.iter_num += 1
+        return outs[0].clone()            # the static output buffer is overwritten by the next replay
 
     def eval_step(self, inputs, labels):
         inputs, labels = self._to_device(inputs, labels)
@@ -147,6 +195,8 @@ class Trainer():
             for phase in self.phases:
                 train = phase == 'train'
                 if train:
+                    if self._dev_sched:
+                        self.optimizer.sync_host()          # the LR lives on the device in graph mode
                     for group in self.optimizer.param_groups:
                         print("LR", group['lr'])
                         log.write(f"LR {group['lr']}\n")

@@ -43,7 +43,17 @@ __device__ inline int find_desc(const D* d, int n, int blk) {
     return lo;
 }
 
-struct SgdArgs { float lr, momentum, omd, wd; int nesterov, first; };   // omd = 1 - dampening
+// Device-resident hyper-parameters of one param group (mirrors umi_optim_hyper, include/unetmi.h): what a captured HIP graph
+// must NOT freeze.  The doubles are the state; the floats are what the update kernel reads, derived by hyper_pre_kernel
+// with the roundings torch applies to its Python doubles.
+struct Hyper {
+    double lr, base_lr, iter, max_iter, power, adam_t, beta1, beta2;
+    float lr_f, step_size_f, bc2_sqrt_f, pad_;
+    double pad2_[2];
+};
+static_assert(sizeof(Hyper) == 96, "umi_optim_hyper is 96 bytes");
+
+struct SgdArgs { float lr, momentum, omd, wd; int nesterov, first; const Hyper* hp; };   // omd = 1 - dampening
 
 __device__ inline void sgd_one(float& p, float g, float& m, const SgdArgs a) {
     if (a.wd != 0.f) g = fmaf(a.wd, p, g);                            // grad.add(param, alpha=wd)
@@ -58,7 +68,7 @@ __device__ inline void sgd_one(float& p, float g, float& m, const SgdArgs a) {
     p = fmaf(-a.lr, g, p);                                             // param.add_(grad, alpha=-lr)
 }
 
-struct AdamArgs { float step_size, omb1, beta2, omb2, bc2_sqrt, eps, wd; };   // omb = 1 - beta, rounded from double
+struct AdamArgs { float step_size, omb1, beta2, omb2, bc2_sqrt, eps, wd; const Hyper* hp; };   // omb = 1 - beta, rounded from double
 
 __device__ inline void adam_one(float& p, float g, float& m, float& v, const AdamArgs a) {
     if (a.wd != 0.f) g = fmaf(a.wd, p, g);                            // grad.add(param, alpha=wd)  (L2, not AdamW)
@@ -70,6 +80,10 @@ __device__ inline void adam_one(float& p, float g, float& m, float& v, const Ada
 
 template <bool ADAM, typename A>
 __global__ __launch_bounds__(256) void optim_multi_kernel(const OptDesc* __restrict__ descs, int n_desc, A a) {
+    if (a.hp) {                               // learning rate / bias corrections from device memory (graph-safe)
+        if constexpr (ADAM) { a.step_size = a.hp->step_size_f; a.bc2_sqrt = a.hp->bc2_sqrt_f; }
+        else a.lr = a.hp->lr_f;
+    }
     const int blk = blockIdx.x;
     const OptDesc d = descs[find_desc(descs, n_desc, blk)];
     const long base = (long)(blk - d.blk0) * OPT_BLOCK;
@@ -180,7 +194,7 @@ extern "C" int umi_optim_sgd_multi(const void* descs, int n_desc, int total_bloc
                                    double dampening, double weight_decay, int nesterov, int first_step,
                                    umi_stream_t stream) {
     if (!descs || n_desc <= 0 || total_blocks <= 0) return UMI_ERR_BADARG;
-    SgdArgs a{(float)lr, (float)momentum, (float)(1.0 - dampening), (float)weight_decay, nesterov, first_step};
+    SgdArgs a{(float)lr, (float)momentum, (float)(1.0 - dampening), (float)weight_decay, nesterov, first_step, nullptr};
     hipLaunchKernelGGL((optim_multi_kernel<false, SgdArgs>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const OptDesc*)descs, n_desc, a);
     UMI_LAUNCH_CHECK();
@@ -191,7 +205,63 @@ extern "C" int umi_optim_adam_multi(const void* descs, int n_desc, int total_blo
                                     double beta2, double bc2_sqrt, double eps, double weight_decay, umi_stream_t stream) {
     if (!descs || n_desc <= 0 || total_blocks <= 0) return UMI_ERR_BADARG;
     AdamArgs a{(float)step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps,
-               (float)weight_decay};
+               (float)weight_decay, nullptr};
+    hipLaunchKernelGGL((optim_multi_kernel<true, AdamArgs>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const OptDesc*)descs, n_desc, a);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// ---- device-resident hyper-parameters (graph-safe learning rate / Adam step count) ------------------------------------
+__global__ void hyper_pre_kernel(Hyper* h, int adam) {
+    if (adam) {                                   // torch.optim.Adam: step += 1; bias corrections in double, then rounded
+        const double t = h->adam_t + 1.0;
+        h->adam_t = t;
+        const double bc1 = 1.0 - pow(h->beta1, t), bc2 = 1.0 - pow(h->beta2, t);
+        h->step_size_f = (float)(h->lr / bc1);
+        h->bc2_sqrt_f = (float)sqrt(bc2);
+    }
+    h->lr_f = (float)h->lr;
+}
+// reference Trainer.py:722-726: lr = base_lr * (1 - iter_num / max_iterations) ** 0.9 with the PRE-increment iter_num, written
+// after the optimizer step; then iter_num += 1
+__global__ void hyper_poly_kernel(Hyper* h) {
+    h->lr = h->base_lr * pow(1.0 - h->iter / h->max_iter, h->power);
+    h->iter += 1.0;
+}
+
+extern "C" size_t umi_optim_hyper_bytes(void) { return sizeof(Hyper); }
+
+extern "C" int umi_optim_hyper_pre(void* hyper, int adam, umi_stream_t stream) {
+    if (!hyper || ((uintptr_t)hyper & 7)) return UMI_ERR_BADARG;
+    hipLaunchKernelGGL(hyper_pre_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (Hyper*)hyper, adam);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_optim_hyper_poly(void* hyper, umi_stream_t stream) {
+    if (!hyper || ((uintptr_t)hyper & 7)) return UMI_ERR_BADARG;
+    hipLaunchKernelGGL(hyper_poly_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (Hyper*)hyper);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_optim_sgd_multi_dev(const void* descs, int n_desc, int total_blocks, const void* hyper, double momentum,
+                                       double dampening, double weight_decay, int nesterov, int first_step,
+                                       umi_stream_t stream) {
+    if (!descs || !hyper || n_desc <= 0 || total_blocks <= 0) return UMI_ERR_BADARG;
+    SgdArgs a{0.f, (float)momentum, (float)(1.0 - dampening), (float)weight_decay, nesterov, first_step, (const Hyper*)hyper};
+    hipLaunchKernelGGL((optim_multi_kernel<false, SgdArgs>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const OptDesc*)descs, n_desc, a);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_optim_adam_multi_dev(const void* descs, int n_desc, int total_blocks, const void* hyper, double beta1,
+                                        double beta2, double eps, double weight_decay, umi_stream_t stream) {
+    if (!descs || !hyper || n_desc <= 0 || total_blocks <= 0) return UMI_ERR_BADARG;
+    AdamArgs a{0.f, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 1.f, (float)eps, (float)weight_decay,
+               (const Hyper*)hyper};
     hipLaunchKernelGGL((optim_multi_kernel<true, AdamArgs>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const OptDesc*)descs, n_desc, a);
     UMI_LAUNCH_CHECK();

@@ -105,6 +105,11 @@ SIGNATURES = {
     "umi_optim_sgd_multi": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_int, c_void_p]),
     "umi_optim_adam_multi": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_double,
                                      c_void_p]),
+    "umi_optim_hyper_bytes": (c_size_t, []),
+    "umi_optim_hyper_pre": (c_int, [c_void_p, c_int, c_void_p]),
+    "umi_optim_hyper_poly": (c_int, [c_void_p, c_void_p]),
+    "umi_optim_sgd_multi_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_double, c_double, c_double, c_int, c_int, c_void_p]),
+    "umi_optim_adam_multi_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_double, c_double, c_double, c_double, c_void_p]),
     "umi_pack_block_elems": (c_int, []),
     "umi_pack_kn_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "umi_add2_relu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_long, c_int, c_int,
