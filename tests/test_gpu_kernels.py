@@ -420,7 +420,8 @@ def _ref_preprocess(img):
 
 
 @pytest.mark.parametrize("shape,dtype", [((37, 53), "uint8"), ((64, 48, 3), "uint8"), ((33, 31, 3), "float32"),
-                                         ((512, 512), "uint8")])
+                                         ((512, 512), "uint8"), ((20, 24, 4), "uint8"), ((18, 22, 2), "float32"),
+                                         ((16, 16, 1), "uint8")])      # every HWC input is channel-reversed, as in the reference
 def test_znorm_preprocess_matches_numpy(shape, dtype):
     _gpu()
     import numpy as np

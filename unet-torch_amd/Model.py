@@ -70,11 +70,14 @@ def _run_tape(module, inputs, build):
     dtype = module._umi_dtype()
     N, _, H, W = inputs[0].shape
 
+    uses_dropout = any(isinstance(m_, nn.Dropout) for m_ in module.modules())
+    seed, seed_dev = G.dropout_seeds(module, inputs[0].device, module.training and uses_dropout)
+
     def run(record, in_needs):
         tape = G.Tape(dtype, training=module.training, record=record,
                       loss_scale=G.default_loss_scale(dtype, N * H * W),
                       grad_sink=getattr(module, "_umi_grad_sink", None) if record else None,
-                      pack_cache=G.pack_cache_of(module))
+                      pack_cache=G.pack_cache_of(module), seed=seed, seed_dev=seed_dev)
         acts = [tape.input_nchw(x, needs_grad=need) for x, need in zip(inputs, in_needs)]
         out_act = build(tape, *acts)
         tape.finish_forward()

@@ -274,16 +274,9 @@ class VisionTransformer(nn.Module):
         dtype = self._umi_dtype()
         N, _, H, W = x.shape
         cfg = self.config
-        self._step += 1
-        step = self._step
-        seed_dev = None
-        if self.training and x.is_cuda:
-            # device-side step counter for the dropout streams: advanced by a device op, so it also advances when this
-            # forward is replayed from a captured HIP graph (where the host-side `step` is frozen at capture time)
-            if getattr(self, "_drop_step", None) is None or self._drop_step.device != x.device:
-                self._drop_step = torch.zeros(1, dtype=torch.int32, device=x.device)
-            self._drop_step.add_(1)
-            seed_dev = self._drop_step
+        # dropout streams: host seed drawn once per model from torch's generator + a device-side step counter that also
+        # advances when this forward is replayed from a captured HIP graph (umi.graph.dropout_seeds)
+        step, seed_dev = G.dropout_seeds(self, x.device, self.training)
 
         def run(record, in_needs):
             tape = TUTape(dtype, training=self.training, record=record, seed=step, seed_dev=seed_dev,

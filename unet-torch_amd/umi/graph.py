@@ -48,8 +48,11 @@ class Act:
 
 
 class Tape:
-    def __init__(self, dtype, training, record, loss_scale=1.0, grad_sink=None, pack_cache=None):
+    def __init__(self, dtype, training, record, loss_scale=1.0, grad_sink=None, pack_cache=None, seed=0, seed_dev=None):
         self.dtype = dtype
+        self._seed = int(seed)            # dropout streams: host part of the seed (per model, from torch's generator) ...
+        self._seed_dev = seed_dev         # ... plus an int32 device counter the kernel adds in, so a step replayed from a
+        self._drop_count = 0              # captured HIP graph (host part frozen) still draws fresh masks
         self.pack_cache = pack_cache      # ops.PackCache of the model that owns the parameters, or None (pack per use)
         self.grad_sink = grad_sink        # umi.ddp.GradReducer (flat buckets + overlapped all-reduce) or None
         self.training = training          # BatchNorm uses batch statistics
@@ -360,15 +363,17 @@ class Tape:
     def dropout(self, a: Act, p):
         """nn.Dropout(p) of the *activated* `a` (reference Model.py:37 after the max-pool, :80-81 after the concat).  The
         consumer transform of `a`, if any, is applied inside the kernel; the result is stored activated.  Mask from the
-        library's own counter-based stream, seeded from torch's CPU generator (so torch.manual_seed reproduces a run)."""
+        library's own counter-based stream: seed = a per-model value drawn once from torch's CPU generator (so
+        torch.manual_seed reproduces a run) + the index of this dropout in the forward + a device-side step counter."""
         if not self.training or p <= 0.0:
             return a
         from . import ops_tu
         N, H, W, C = a.shape
         out = self.alloc(N, H, W, C, device=a.raw.device)
         mask = torch.empty(N * H * W * C, dtype=torch.uint8, device=a.raw.device)
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        ops_tu.dropout(a.raw, out, mask, False, p, seed, a.tx)
+        self._drop_count += 1
+        ops_tu.dropout(a.raw, out, mask, False, p, (self._seed * 7919 + self._drop_count) & 0x7FFFFFFF, a.tx,
+                       seed_dev=self._seed_dev)
         o = Act(out, None)
         if self.record:
             def bwd():
@@ -473,6 +478,24 @@ class Tape:
         if self.loss_scale != 1.0:
             g = g / self.loss_scale
         return g.contiguous()
+
+
+def dropout_seeds(module, device, training):
+    """(host seed, device step counter) for the dropout streams of `module`'s forward.  The host part is drawn ONCE per model
+    from torch's CPU generator (reproducible under torch.manual_seed, different between the seeds of a sweep and between a
+    run and its resumption); the device counter advances by a device op on every training forward, also under HIP-graph
+    replay, where anything computed on the host is frozen at capture time."""
+    if not training or device.type != "cuda":
+        return 0, None
+    if getattr(module, "_drop_base", None) is None:
+        module._drop_base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    ctr = getattr(module, "_drop_step", None)
+    if ctr is None or ctr.device != device:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("first training forward inside a HIP-graph capture; run one eager step first")
+        ctr = module._drop_step = torch.zeros(1, dtype=torch.int32, device=device)
+    ctr.add_(1)
+    return module._drop_base, ctr
 
 
 def pack_cache_of(module):

@@ -16,9 +16,12 @@ from . import ops
 
 def preprocess(img, reverse_channels=None):
     """Per-channel z-normalisation of one image, HWC (or HW) -> [1,C,H,W] fp32 (reference `preprocess`: mean / np.std over
-    H,W in fp64; 3-channel images are also flipped BGR -> RGB, `reverse_channels` defaults to that rule)."""
+    H,W in fp64).  The reference reverses the channel order of EVERY 3-D (HWC) input (`transpose((2, 0, 1))[::-1]`,
+    test_mc3serousv5.py:124: BGR -> RGB for cv2 images, but 2- and 4-channel inputs are reversed as well) and leaves 2-D
+    (HW) inputs alone; `reverse_channels=None` follows that rule, True / False override it."""
     if isinstance(img, np.ndarray):
         img = torch.from_numpy(np.ascontiguousarray(img))
+    was_hwc = img.dim() == 3
     if img.dim() == 2:
         img = img.unsqueeze(-1)
     if img.dim() != 3 or img.shape[2] > 4:
@@ -28,7 +31,7 @@ def preprocess(img, reverse_channels=None):
     img = img.contiguous().to("cuda", non_blocking=True)
     H, W, C = img.shape
     if reverse_channels is None:
-        reverse_channels = C == 3
+        reverse_channels = was_hwc
     out = torch.empty((1, C, H, W), dtype=torch.float32, device=img.device)
     nbytes = L.fn("umi_znorm_ws_bytes")()
     ws = ops.workspace(nbytes, img.device)
