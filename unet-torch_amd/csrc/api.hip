@@ -17,7 +17,7 @@ int umi_conv_wgrad_generic(const void* x, int ldx, const void* txa, const void* 
 // conv_mfma.hip
 bool umi_conv3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
                          int ldx, int ldy, int in_dtype, int out_dtype, int flags, const float* bias);
-int umi_conv3x3_mfma_stat_rows(int N, int Ho, int Wo, int Co);
+int umi_conv3x3_mfma_stat_rows(int N, int Ho, int Wo, int Ci, int Co, int ldx);
 int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
                      int N, int H, int W, int Ci, int Co, hipStream_t s);
 // conv1x1_mfma.hip
@@ -109,7 +109,7 @@ extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int
     const bool head = !mfma && !mfma1 && !dgs && !stem && out_dtype == UMI_F16 &&
                       umi_head_fwd_ok(Ci, Co, R, S, stride, pad, ldx, in_dtype, out_dtype, flags);
     if (stat_rows)
-        *stat_rows = mfma ? umi_conv3x3_mfma_stat_rows(N, H, W, Co)
+        *stat_rows = mfma ? umi_conv3x3_mfma_stat_rows(N, H, W, Ci, Co, ldx)
                           : (stem ? umi_stem_stat_rows(N, H, W)
                                   : (head ? umi_head_stat_rows((long)N * H * W, Ci) : umi_cdiv((long)N * Ho * Wo, 64)));
     return UMI_OK;
