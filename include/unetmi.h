@@ -51,9 +51,9 @@ const char* umi_arch(void);          /* "gfx950" */
 
 /* Tuning knob (process-wide): which kernel serves the 3x3 / stride-1 matrix-core path of umi_conv_fwd and
  * umi_conv_dgrad_bnred: 1 = csrc/conv_mfma.hip, 2 / 3 / 4 = csrc/conv_mfma2.hip (halo staged after tap column 0 / 1 /
- * paired chunk loads), 5 = csrc/conv_mfma3.hip (persistent workgroups).  All produce bit-identical outputs; only the
+ * paired chunk loads), 5 = csrc/conv_mfma3.hip (persistent workgroups), 6 = csrc/conv_mfma4.hip (persistent, 8 waves in anti-phase).  All produce bit-identical outputs; only the
  * statistics partial-row count reported by umi_conv_fwd_plan differs, so change it between whole convolutions only.  Returns
- * the previous value; values outside 1..5 only query.  The initial value is
+ * the previous value; values outside 1..6 only query.  The initial value is
  * the library default or env UMI_CONV3X3_IMPL. */
 int umi_tune_conv3x3_impl(int impl);
 

@@ -421,20 +421,28 @@ int umi_conv3x3_mfma3(const void* x, int ldx, const void* tx, const void* wp8, v
                       int W, int Ci, int Co, const void* bn_y, int bn_ld, const void* bn_tx, const float* bn_rstd,
                       hipStream_t s);
 
+// conv_mfma4.hip: persistent 8-wave workgroups, two wave groups in anti-phase, bit-identical outputs
+int umi_conv3x3_mfma4_stat_rows(int N, int H, int W);
+bool umi_conv3x3_mfma4_ok(int N, int H, int W, int Ci, int Co, int ldx);
+int umi_conv3x3_mfma4(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H,
+                      int W, int Ci, int Co, const void* bn_y, int bn_ld, const void* bn_tx, const float* bn_rstd,
+                      hipStream_t s);
+
 // Which kernel serves the 3x3 MFMA path: 1 = conv_mfma.hip, 2 / 3 / 4 = conv_mfma2.hip (variants), 5 = conv_mfma3.hip
-// (persistent; shapes it does not take fall back to 1).  Process-wide tuning
+// (persistent), 6 = conv_mfma4.hip (persistent, 8 waves in anti-phase); shapes 5 / 6 do not take fall back to 1.  Process-wide tuning
 // knob (env UMI_CONV3X3_IMPL at load, umi_tune_conv3x3_impl at run time for same-process A/B timing); the statistics
 // partial-row count of umi_conv_fwd_plan follows it, so set it between whole convolutions only.
 static int g_impl = [] { const char* e = getenv("UMI_CONV3X3_IMPL"); return e ? atoi(e) : 1; }();
 extern "C" int umi_tune_conv3x3_impl(int impl) {
     const int old = g_impl;
-    if (impl >= 1 && impl <= 5) g_impl = impl;
+    if (impl >= 1 && impl <= 6) g_impl = impl;
     return old;
 }
 
 static int pick_th(int Co) { return use_bn128(Co) ? 8 : 16; }
 
 int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Ci, int Co, int ldx) {
+    if (g_impl == 6 && umi_conv3x3_mfma4_ok(N, H, W, Ci, Co, ldx)) return umi_conv3x3_mfma4_stat_rows(N, H, W);
     if (g_impl == 5 && umi_conv3x3_mfma3_ok(N, H, W, Ci, Co, ldx)) return umi_conv3x3_mfma3_stat_rows(N, H, W);
     if (g_impl >= 2 && g_impl <= 4) return umi_conv3x3_mfma2_stat_rows(N, H, W);
     const int th = pick_th(Co);
@@ -443,6 +451,8 @@ int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Ci, int Co, int ldx) {
 
 int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
                      int N, int H, int W, int Ci, int Co, hipStream_t s) {
+    if (g_impl == 6 && umi_conv3x3_mfma4_ok(N, H, W, Ci, Co, ldx))
+        return umi_conv3x3_mfma4(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, 0, nullptr, nullptr, s);
     if (g_impl == 5 && umi_conv3x3_mfma3_ok(N, H, W, Ci, Co, ldx))
         return umi_conv3x3_mfma3(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, 0, nullptr, nullptr, s);
     if (g_impl >= 2 && g_impl <= 4)
@@ -455,6 +465,8 @@ int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, vo
 int umi_conv3x3_mfma_bnred(const void* dy, int lddy, const void* wp8, void* da, int ldda, const void* ybn, int ldybn,
                            const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
                            hipStream_t s) {
+    if (g_impl == 6 && umi_conv3x3_mfma4_ok(N, H, W, Ci, Co, lddy))
+        return umi_conv3x3_mfma4(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, ybn, ldybn, txbn, rstd, s);
     if (g_impl == 5 && umi_conv3x3_mfma3_ok(N, H, W, Ci, Co, lddy))
         return umi_conv3x3_mfma3(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, ybn, ldybn, txbn, rstd, s);
     if (g_impl >= 2 && g_impl <= 4)
