@@ -227,6 +227,40 @@ def test_unet_fp16_close_to_oracle(golden_dir, name):
     assert med < 1.5 * med_floor + 0.01 and max(errs.values()) < 2.0 * max(floor.values()) + 0.02
 
 
+@pytest.mark.parametrize("cin,ncls", [(1, 2), (3, 4)])
+def test_unet_fp16_feat64_benchmark_widths(cin, ncls):
+    """The benchmarked path at the benchmark's channel widths: UNet(1,2,64) / UNet(3,4,64) in fp16 storage, 2 x C x 64 x 64
+    (64 .. 1024 channels: every tile configuration of the matrix-core kernels, no layer on the generic VALU kernels --
+    asserted through UMI_TRACE_GENERIC in a child process, tools/check_fp16_feat64.py) against the CPU oracle in fp32 and
+    with the same fp16 rounding points:
+      * logits within 2e-2 of the logit scale (fp32 oracle) and 1e-2 (fp16 oracle); loss within 5e-3;
+      * argmax masks identical on every pixel whose top-2 margin exceeds 4x the worst logit error (near-ties may flip);
+      * gradients: finite; cosine vs the fp32 oracle > 0.9 for every tensor; relative L2 vs the fp16 oracle bounded by
+        the oracle's own rounding-chaos floor (median < 1.5x floor + 0.01, worst < 2x worst floor + 0.02) and by an
+        absolute 0.5 for the worst tensor / 0.25 for the median (measured: median 0.16 against a floor of 0.12).
+    The measured values of one such run are committed as profiles/r02_fp16_feat64_parity.json."""
+    _need_gpu()
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UMI_TRACE_GENERIC="1")
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "check_fp16_feat64.py"), str(cin), str(ncls)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "[umi generic" not in r.stderr, [l for l in r.stderr.splitlines() if "[umi generic" in l][:8]
+    m = json.loads([l for l in r.stdout.splitlines() if l.startswith("FP16_FEAT64 ")][-1][len("FP16_FEAT64 "):])
+    print(m)
+    assert m["grads_finite"]
+    assert m["logits_max_err_over_scale_vs_fp32_oracle"] < 2e-2 and m["logits_max_err_over_scale_vs_fp16_oracle"] < 1e-2
+    assert abs(m["loss"] - m["loss_fp32_oracle"]) < 5e-3 and abs(m["loss"] - m["loss_fp16_oracle"]) < 5e-3
+    assert m["argmax_mismatch_clear"] == 0 and m["pixels_clear_of_near_ties"] > 0.5 * m["pixels"]
+    gq, fl = m["grad_rel_l2_vs_fp16_oracle"], m["grad_rel_l2_fp16_oracle_self_noise_floor"]
+    assert gq["median"] < 1.5 * fl["median"] + 0.01 and gq["worst"] < 2.0 * fl["worst"] + 0.02, (gq, fl)
+    assert gq["median"] < 0.25 and gq["worst"] < 0.5, gq
+    assert m["grad_cosine_vs_fp32_oracle"]["worst"] > 0.9, m["grad_cosine_vs_fp32_oracle"]
+
+
 def test_unet_config1_scale_fp32(golden_dir):
     """Config 1 shape (UNet(1,2,64), B=2, 256x256): logits signature + argmax mask vs the reference."""
     _need_gpu()
