@@ -98,7 +98,10 @@ def test_layer_norm_gelu_pool_bilinear_fp32():
 
 @pytest.mark.parametrize("dt,tol,N,heads,D", [(torch.float32, 2e-5, 50, 4, 16), (torch.float16, 3e-3, 196, 3, 64),
                                                  (torch.float16, 3e-3, 301, 2, 64), (torch.float16, 3e-3, 17, 1, 64),
-                                                 (torch.float16, 3e-3, 40, 2, 32)])
+                                                 (torch.float16, 3e-3, 40, 2, 32),
+                                                 # 1,024 tokens x 12 heads x 64: the ViT-B/16 attention of a 512 x 512 image
+                                                 # (BASELINE configs[4], reference vit_seg_modeling.py:82-88)
+                                                 (torch.float16, 3e-3, 1024, 12, 64), (torch.float32, 2e-5, 1024, 2, 64)])
 def test_attention_fwd_bwd(dt, tol, N, heads, D):
     lib, ops, T = _gpu()
     g = torch.Generator().manual_seed(3)

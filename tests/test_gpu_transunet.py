@@ -124,6 +124,52 @@ def test_transunet_r50_vit_b16_224_fp32(golden_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_transunet_r50_vit_b16_512(golden_dir, dtype):
+    """BASELINE configs[4] shape: R50-ViT-B/16 at 512 x 512, B = 1 -- 1,024 tokens through the MFMA attention (fp16) and the
+    ResNet's odd-size skip (127 x 127 zero-padded to 128 x 128, reference vit_seg_modeling_resnet_skip.py:142-160) --
+    against the reference's own outputs (fixture: logits signature, loss, per-parameter gradient norms).
+    fp32: the bars of the 224 case.  fp16 storage: logits within 3e-2 of scale, loss within 5e-3, gradient norms of the
+    large tensors within 25 % (masks flip under fp16 rounding; cosine is checked on the miniature config)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    import loss as L
+    from TransUnet.vit_seg_modeling import VisionTransformer
+    g = np.load(os.path.join(golden_dir, "transunet_r50_b16_512.npz"))
+    cfg = ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)
+    L.CLASS_NUMBER = 2
+    m = VisionTransformer(product_config(cfg, 512), img_size=512, num_classes=2, compute_dtype=dtype)
+    assert len(m.state_dict()) == 409 and m.state_dict()["transformer.embeddings.position_embeddings"].shape[1] == 1024
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=int(g["seed"]), negative_gamma=False))
+    m.to(DEV).train()
+    x, lab = recipe.synthetic_batch(1, 1, 512, 512, 2, seed=int(g["seed"]))
+    logits = m(x.to(DEV))
+    loss = L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc")
+    loss.backward()
+    assert tuple(logits.shape) == (1, 2, 512, 512)
+    s = sig(logits.cpu())
+    if dtype == "fp32":
+        np.testing.assert_allclose(s[[0, 2]], g["logits_sig"][[0, 2]], rtol=2e-4)
+        np.testing.assert_allclose(s[3:], g["logits_sig"][3:], rtol=1e-3, atol=1e-3 * s[0] / 300)
+        assert abs(loss.item() - float(g["loss0"])) < 2e-5
+    else:
+        scale = np.abs(g["logits_sig"][3:]).max()
+        np.testing.assert_allclose(s[[0, 2]], g["logits_sig"][[0, 2]], rtol=2e-2)
+        assert np.abs(s[3:] - g["logits_sig"][3:]).max() < 3e-2 * max(scale, s[0] / 700)
+        assert abs(loss.item() - float(g["loss0"])) < 5e-3
+    bad = []
+    for k, p in m.named_parameters():
+        ref_norm = float(g["grad_sig." + k][0])
+        assert torch.isfinite(p.grad).all(), k
+        if ref_norm < 1e-7 or (dtype == "fp16" and p.numel() < 4096):
+            continue
+        tol = 1e-2 if dtype == "fp32" else 0.25
+        if abs(p.grad.double().norm().item() - ref_norm) > tol * ref_norm:
+            bad.append((k, p.grad.double().norm().item(), ref_norm))
+    assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
 def test_transunet_small_fp16_runs_close(golden_dir):
     """fp16 storage: logits within 3e-2 of logit scale of the fp32 reference, finite grads, cosine > 0.9 on big tensors."""
     if not torch.cuda.is_available():

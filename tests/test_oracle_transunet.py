@@ -12,6 +12,8 @@ CASES = {
     "transunet_small": (lambda: ref_transunet.small_config(2)),
     "transunet_small_rgb4": (lambda: ref_transunet.small_config(4)),
     "transunet_r50_b16_224": (lambda: ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)),
+    # BASELINE configs[4] shape: 1,024 tokens, 127 -> 128 zero-pad of the 1/4-scale ResNet skip (resnet_skip.py:147-158)
+    "transunet_r50_b16_512": (lambda: ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)),
 }
 
 

@@ -348,9 +348,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--big", action="store_true", help="also config-1 scale UNet(1,2,64) 256^2")
+    ap.add_argument("--tu512", action="store_true", help="only the R50-ViT-B/16 @512 TransUNet fixture (BASELINE configs[4] shape)")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     Model, loss_mod, Trainer = import_reference()
+    if a.tu512:
+        from tools import gen_golden_transunet
+        gen_golden_transunet.run(import_reference, sig, meta, GOLD, only512=True)
+        return
     if a.only in (None, "blocks"):
         gen_blocks(Model)
     if a.only in (None, "unet"):

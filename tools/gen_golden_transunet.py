@@ -86,9 +86,15 @@ def _case_multitask(vsm, loss_mod, sig, meta, GOLD, name, cls_name, cfg, img, B,
     print(f"wrote {name}.npz keys={out['n_keys']} loss0={out['loss0']:.6f}")
 
 
-def run(import_reference, sig, meta, GOLD, big=False):
+def run(import_reference, sig, meta, GOLD, big=False, only512=False):
     _, loss_mod, _ = import_reference()
     from TransUnet import vit_seg_modeling as vsm
+    if only512:
+        # BASELINE configs[4] shape: R50-ViT-B/16 at 512 x 512 (1,024 tokens; the ResNet's 127 -> 128 zero-pad fix-up of the
+        # 1/4-scale skip, reference vit_seg_modeling_resnet_skip.py:147-158), B = 1, signatures only
+        cfg = ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)
+        _case(vsm, loss_mod, sig, meta, GOLD, "transunet_r50_b16_512", cfg, 512, 1, 1, 34, False)
+        return
     _case(vsm, loss_mod, sig, meta, GOLD, "transunet_small", ref_transunet.small_config(2), 64, 2, 1, 31, True)
     _case(vsm, loss_mod, sig, meta, GOLD, "transunet_small_rgb4", ref_transunet.small_config(4), 96, 1, 3, 32, True)
     _case_multitask(vsm, loss_mod, sig, meta, GOLD, "transunet_small_multitask", "VisionTransformerMultitask",
