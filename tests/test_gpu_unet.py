@@ -457,6 +457,51 @@ def test_fused_optimizer_and_pack_cache_leave_the_training_trajectory_unchanged(
         torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("name,pcls,rcls", [("unet_multitask_1_2_8_s10", "UNet_multitask", "RefUNetMultitask"),
+                                            ("unet_attention_1_2_8_s16", "UNet_attention", "RefUNetAttention")])
+def test_variant_unpicked_seeds(golden_dir, name, pcls, rcls):
+    """The variant fixtures of the two tests below were generated on seeds screened to be free of ReLU near-ties on both
+    sides, which is what lets them carry a 2e-3 per-tensor gradient bar.  These two seeds were NOT screened (seed 10 is one
+    where the reference's own fp32 and fp64 runs disagree on a mask; 16 is one where this build's summation order does).
+    Stated bound for such seeds, fp32 path: logits still within 1e-4 of the reference's (fixture), loss within 1e-4; gradients
+    within 3e-2 relative L2 for EVERY tensor and 2e-3 for the median tensor (one flipped ReLU element moves the tensors
+    downstream of it by 1e-3 .. 1e-2)."""
+    _need_gpu()
+    import Model
+    import loss as L
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cin, ncls, feat = int(g["cin"]), int(g["ncls"]), int(g["feat"])
+    B, H, W, seed = int(g["B"]), int(g["H"]), int(g["W"]), int(g["seed"])
+    ref = getattr(ref_unet, rcls)(cin, ncls, feat, False)
+    ref.load_state_dict(recipe.fill_state_dict(ref.state_dict(), seed=seed))
+    x, lab1 = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed)
+    _, lab2 = recipe.synthetic_batch(B, cin, H, W, ncls, seed=seed + 100)
+    L.CLASS_NUMBER = ncls
+    m = getattr(Model, pcls)(cin, ncls, feat, False, compute_dtype="fp32")
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).train()
+    ref.train()
+    out, rout = m(x.to(DEV)), ref(x)
+    if isinstance(out, tuple):
+        loss = L.calc_loss(out[0], lab1.to(DEV), loss_type="dice_bce_mc") + L.calc_loss(out[1], lab2.to(DEV), loss_type="dice_bce_mc")
+        rloss = ref_unet.dice_bce_mc(rout[0], lab1, ncls) + ref_unet.dice_bce_mc(rout[1], lab2, ncls)
+        pairs = [(out[0], g["logits1"]), (out[1], g["logits2"])]
+    else:
+        loss = L.calc_loss(out, lab1.to(DEV), loss_type="dice_bce_mc")
+        rloss = ref_unet.dice_bce_mc(rout, lab1, ncls)
+        pairs = [(out, g["logits"])]
+    loss.backward()
+    rloss.backward()
+    for o, gl in pairs:
+        np.testing.assert_allclose(o.detach().cpu().numpy(), gl, rtol=1e-4, atol=1e-4 * float(np.abs(gl).max()))
+    assert abs(loss.item() - float(g["loss0"])) < 1e-4
+    errs = {k: rel_err(p.grad, rp.grad) for (k, p), (_, rp) in zip(m.named_parameters(), ref.named_parameters())
+            if rp.grad.abs().max() > 1e-6}
+    print(name, "grad rel-L2: median", float(np.median(list(errs.values()))), "worst", max(errs.items(), key=lambda kv: kv[1]))
+    assert max(errs.values()) < 3e-2, max(errs.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(errs.values()))) < 2e-3
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_unet_multitask_parity(golden_dir, dtype):
     """`Model.UNet_multitask` (two decoders on one tape, encoder gradients summed) against the

@@ -366,8 +366,12 @@ def main():
                           full_logits=False, steps=1)
     if a.only in (None, "multitask"):
         gen_unet_multitask(Model, loss_mod)
+        # a seed that was NOT screened for ReLU near-ties (it is one of those where the reference's own fp32 and fp64 runs
+        # disagree on a mask): carries the looser, stated gradient bound of tests/test_gpu_unet.py::test_variant_unpicked_seeds
+        gen_unet_multitask(Model, loss_mod, name="unet_multitask_1_2_8_s10", seed=10, steps=1)
     if a.only in (None, "attention"):
         gen_unet_attention(Model, loss_mod)
+        gen_unet_attention(Model, loss_mod, name="unet_attention_1_2_8_s16", seed=16, steps=1)
     if a.only in (None, "trainer"):
         gen_trainer(Model, loss_mod, Trainer)
     if a.only in (None, "trainer_multitask"):
