@@ -69,3 +69,56 @@ def synthetic_batch(batch, channels, height, width, n_classes, seed: int = 1234)
     q = torch.quantile(blur.flatten(), torch.linspace(0, 1, n_classes + 1)[1:-1])
     labels = torch.bucketize(blur[:, 0], q).to(torch.float32)
     return x, labels
+
+
+def synthetic_jax_checkpoint(model, hidden, heads, old_grid, seed=77, cls_token=True):
+    """A seeded stand-in for the JAX ViT / R50 `.npz` checkpoint the reference's `load_from` consumes
+    (`/root/reference/TransUnet/vit_seg_modeling.py:189-224,394-441`, `vit_seg_modeling_resnet_skip.py:76-110`): the key
+    names and array layouts of the published checkpoints (HWIO conv kernels, [hidden, heads, head_dim] attention kernels,
+    [1, 1 + grid^2, hidden] position embedding with a class token), values from numpy's generator.  Walks the MODEL's own
+    module tree, which the reference and the product share, so both sides draw identical arrays.  The real checkpoint is
+    not in the reference tree and cannot be downloaded (no network)."""
+    import numpy as np
+    g = np.random.default_rng(seed)
+    w = {}
+
+    def r(*shape):
+        return (g.standard_normal(shape) * 0.1).astype(np.float32)
+
+    def conv(key, weight):
+        O, I, kh, kw = weight.shape
+        w[key] = r(kh, kw, I, O)
+
+    emb = model.transformer.embeddings
+    conv("embedding/kernel", emb.patch_embeddings.weight)
+    w["embedding/bias"] = r(emb.patch_embeddings.weight.shape[0])
+    w["Transformer/encoder_norm/scale"], w["Transformer/encoder_norm/bias"] = r(hidden), r(hidden)
+    w["Transformer/posembed_input/pos_embedding"] = r(1, (1 if cls_token else 0) + old_grid * old_grid, hidden)
+    hd = hidden // heads
+    for i, blk in enumerate(model.transformer.encoder.layer):
+        root = f"Transformer/encoderblock_{i}"
+        for n in ("query", "key", "value"):
+            w[f"{root}/MultiHeadDotProductAttention_1/{n}/kernel"] = r(hidden, heads, hd)
+            w[f"{root}/MultiHeadDotProductAttention_1/{n}/bias"] = r(heads, hd)
+        w[f"{root}/MultiHeadDotProductAttention_1/out/kernel"] = r(heads, hd, hidden)
+        w[f"{root}/MultiHeadDotProductAttention_1/out/bias"] = r(hidden)
+        mlp = blk.ffn.fc1.weight.shape[0]
+        w[f"{root}/MlpBlock_3/Dense_0/kernel"], w[f"{root}/MlpBlock_3/Dense_0/bias"] = r(hidden, mlp), r(mlp)
+        w[f"{root}/MlpBlock_3/Dense_1/kernel"], w[f"{root}/MlpBlock_3/Dense_1/bias"] = r(mlp, hidden), r(hidden)
+        for ln in ("LayerNorm_0", "LayerNorm_2"):
+            w[f"{root}/{ln}/scale"], w[f"{root}/{ln}/bias"] = r(hidden), r(hidden)
+    hm = emb.hybrid_model
+    conv("conv_root/kernel", hm.root.conv.weight)
+    C = hm.root.conv.weight.shape[0]
+    w["gn_root/scale"], w["gn_root/bias"] = r(1, 1, 1, C), r(1, 1, 1, C)
+    for bname, block in hm.body.named_children():
+        for uname, unit in block.named_children():
+            for c, gn in (("conv1", "gn1"), ("conv2", "gn2"), ("conv3", "gn3")):
+                conv(f"{bname}/{uname}/{c}/kernel", getattr(unit, c).weight)
+                C = getattr(unit, c).weight.shape[0]
+                w[f"{bname}/{uname}/{gn}/scale"], w[f"{bname}/{uname}/{gn}/bias"] = r(1, 1, 1, C), r(1, 1, 1, C)
+            if hasattr(unit, "downsample"):
+                conv(f"{bname}/{uname}/conv_proj/kernel", unit.downsample.weight)
+                C = unit.downsample.weight.shape[0]
+                w[f"{bname}/{uname}/gn_proj/scale"], w[f"{bname}/{uname}/gn_proj/bias"] = r(1, 1, 1, C), r(1, 1, 1, C)
+    return w

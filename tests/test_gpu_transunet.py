@@ -31,6 +31,28 @@ def rel_err(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+@pytest.mark.parametrize("tag,old_grid", [("zoom", 3), ("drop_cls", 4)])
+def test_load_from_matches_reference(golden_dir, tag, old_grid):
+    """CPU (host logic): `VisionTransformer.load_from` -> `Block.load_from` -> `PreActBottleneck.load_from` (reference
+    vit_seg_modeling.py:189-224,394-441, vit_seg_modeling_resnet_skip.py:76-110) on a synthetic JAX-keyed checkpoint
+    (oracle/recipe.py: HWIO kernels, [hidden, heads, head_dim] attention kernels, class-token position embedding) against
+    the state_dict the REFERENCE's load_from produces from the same arrays (fixture), for both position-embedding paths
+    (3 x 3 grid resized to 4 x 4 with ndimage.zoom; 4 x 4 grid with the class token dropped)."""
+    from TransUnet.vit_seg_modeling import VisionTransformer
+    g = np.load(os.path.join(golden_dir, "transunet_small_load_from.npz"))
+    cfg = ref_transunet.small_config(2)
+    torch.manual_seed(0)
+    m = VisionTransformer(product_config(cfg, 64), img_size=64, num_classes=2)
+    w = recipe.synthetic_jax_checkpoint(m, cfg["hidden_size"], cfg["num_heads"], old_grid, seed=77)
+    assert len(w) == int(g[tag + ".n_ckpt_keys"])
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_from(w)
+    changed = [k for k, v in m.state_dict().items() if not torch.equal(v, before[k])]
+    assert changed == g[tag + ".changed"].tolist()              # exactly the tensors the reference overwrites
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(sig(v.float()), g[f"{tag}.sig." + k], rtol=1e-6, atol=1e-7, err_msg=k)
+
+
 def test_product_transunet_surface_and_init(golden_dir):
     """CPU: constructor, key set/order and init RNG stream equal the reference's (fixture `keys`, `init_sig.*`)."""
     from TransUnet.vit_seg_modeling import CONFIGS, VisionTransformer

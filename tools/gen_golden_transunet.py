@@ -86,9 +86,36 @@ def _case_multitask(vsm, loss_mod, sig, meta, GOLD, name, cls_name, cfg, img, B,
     print(f"wrote {name}.npz keys={out['n_keys']} loss0={out['loss0']:.6f}")
 
 
-def run(import_reference, sig, meta, GOLD, big=False, only512=False):
+def _case_load_from(vsm, sig, meta, GOLD):
+    """state_dict signatures after the REFERENCE's `load_from` (vit_seg_modeling.py:394-441 -> Block.load_from :189-224 ->
+    PreActBottleneck.load_from resnet_skip.py:76-110) of a synthetic JAX-keyed checkpoint (oracle/recipe.py), for the two
+    position-embedding paths a 4 x 4-token model can take: a 3 x 3 grid + class token (bilinear `ndimage.zoom` resize) and a
+    4 x 4 grid + class token (class token dropped).  The real `.npz` is not in the reference tree."""
+    cfg = ref_transunet.small_config(2)
+    out = {}
+    for tag, old_grid in (("zoom", 3), ("drop_cls", 4)):
+        torch.manual_seed(0)
+        m = vsm.VisionTransformer(_ref_config(cfg, 64), img_size=64, num_classes=2)
+        w = recipe.synthetic_jax_checkpoint(m, cfg["hidden_size"], cfg["num_heads"], old_grid, seed=77)
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        m.load_from(w)
+        out[tag + ".n_ckpt_keys"] = len(w)
+        changed = []
+        for k, v in m.state_dict().items():
+            out[f"{tag}.sig." + k] = sig(v.float())
+            if not torch.equal(v, before[k]):
+                changed.append(k)
+        out[tag + ".changed"] = np.array(changed)
+    np.savez_compressed(os.path.join(GOLD, "transunet_small_load_from.npz"), **out, **meta())
+    print("wrote transunet_small_load_from.npz", out["zoom.n_ckpt_keys"], len(out["zoom.changed"]))
+
+
+def run(import_reference, sig, meta, GOLD, big=False, only512=False, only_load_from=False):
     _, loss_mod, _ = import_reference()
     from TransUnet import vit_seg_modeling as vsm
+    if only_load_from:
+        _case_load_from(vsm, sig, meta, GOLD)
+        return
     if only512:
         # BASELINE configs[4] shape: R50-ViT-B/16 at 512 x 512 (1,024 tokens; the ResNet's 127 -> 128 zero-pad fix-up of the
         # 1/4-scale skip, reference vit_seg_modeling_resnet_skip.py:147-158), B = 1, signatures only
@@ -101,6 +128,7 @@ def run(import_reference, sig, meta, GOLD, big=False, only512=False):
                     ref_transunet.small_config(2), 64, 2, 1, 35)
     _case_multitask(vsm, loss_mod, sig, meta, GOLD, "transunet_small_multitask_em", "VisionTransformerMultitaskEM",
                     ref_transunet.small_config(2), 64, 1, 1, 39)
+    _case_load_from(vsm, sig, meta, GOLD)
     if big:
         cfg = ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)
         _case(vsm, loss_mod, sig, meta, GOLD, "transunet_r50_b16_224", cfg, 224, 1, 1, 33, False)
