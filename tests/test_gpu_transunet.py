@@ -259,3 +259,93 @@ def test_transunet_multitask_fp32_parity(golden_dir, name, pcls, rcls):
         e = (p.grad.detach().double().cpu() - rp.grad.double()).norm().item() / (rp.grad.double().norm().item() + 1e-6 / 3e-3)
         worst = max(worst, (k, e), key=lambda t: t[1])
     assert worst[1] < 3e-3, worst
+
+
+@pytest.mark.gpu
+def test_transunet_submodules_run_standalone():
+    """The sub-modules of the TransUNet can be called on their own like the reference's (vit_seg_modeling.py:73-94,113-119,
+    154-165,177-187,237-244,309-315,355-367; vit_seg_modeling_resnet_skip.py:20-25,60-74,142-160): each builds a small HIP
+    tape.  fp32 path against a plain-PyTorch restatement with the module's own parameters, forward and input gradient."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    import torch.nn.functional as F
+    from TransUnet import vit_seg_modeling as vsm
+    from TransUnet import vit_seg_modeling_resnet_skip as rs
+    cfg = product_config(ref_transunet.small_config(2), 64)
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(4)
+    hid, heads = cfg.hidden_size, cfg.transformer["num_heads"]
+
+    def close(a, b, tol=2e-4):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        assert a.shape == b.shape, (a.shape, b.shape)
+        assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-3), (a - b).abs().max().item()
+
+    def with_grad(mod, x, ref_fn, tol=2e-4):
+        import copy
+        mod_cpu = copy.deepcopy(mod).train()
+        mod.to(DEV).train()
+        mod._compute_dtype = "fp32"
+        xd = x.to(DEV).requires_grad_(True)
+        out = mod(xd)
+        out = out[0] if isinstance(out, tuple) else out
+        xr = x.clone().requires_grad_(True)
+        want = ref_fn(mod_cpu, xr)
+        close(out, want, tol)
+        gy = torch.randn(want.shape, generator=g)
+        out.backward(gy.to(DEV))
+        want.backward(gy)
+        close(xd.grad, xr.grad, 5 * tol)
+        for (k, p), (_, rp) in zip(mod.named_parameters(), mod_cpu.named_parameters()):
+            if rp.grad is not None and rp.grad.abs().max() > 1e-6:
+                close(p.grad, rp.grad, 10 * tol)
+
+    def ref_attn(m, x):
+        B, N, C = x.shape
+        sp = lambda t: t.view(B, N, heads, C // heads).permute(0, 2, 1, 3)
+        p = torch.softmax(sp(m.query(x)) @ sp(m.key(x)).transpose(-1, -2) / (C // heads) ** 0.5, -1)
+        return m.out((p @ sp(m.value(x))).permute(0, 2, 1, 3).reshape(B, N, C))
+
+    def ref_mlp(m, x):
+        return m.fc2(F.gelu(m.fc1(x)))
+
+    def ref_block(m, x):
+        h = x + ref_attn(m.attn, F.layer_norm(x, (hid,), m.attention_norm.weight, m.attention_norm.bias, 1e-6))
+        return h + ref_mlp(m.ffn, F.layer_norm(h, (hid,), m.ffn_norm.weight, m.ffn_norm.bias, 1e-6))
+
+    def ref_encoder(m, x):
+        for blk in m.layer:
+            x = ref_block(blk, x)
+        return F.layer_norm(x, (hid,), m.encoder_norm.weight, m.encoder_norm.bias, 1e-6)
+
+    def ref_decoder_block(m, x):
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        for c in (m.conv1, m.conv2):
+            x = F.relu(F.batch_norm(F.conv2d(x, c[0].weight, None, 1, 1), None, None, c[1].weight, c[1].bias, True, 0.1, 1e-5))
+        return x
+
+    def ref_stdconv(m, x):
+        w = m.weight
+        v, mu = torch.var_mean(w, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        return F.conv2d(x, (w - mu) / torch.sqrt(v + 1e-5), None, m.stride, m.padding)
+
+    tok = torch.randn(2, 16, hid, generator=g)
+    with_grad(vsm.Attention(cfg, False), tok, ref_attn)
+    with_grad(vsm.Mlp(cfg), tok, ref_mlp)
+    with_grad(vsm.Block(cfg, False), tok, ref_block)
+    with_grad(vsm.Encoder(cfg, False), tok, ref_encoder, tol=5e-4)
+    with_grad(vsm.DecoderBlock(32, 16), torch.randn(2, 32, 6, 5, generator=g), ref_decoder_block, tol=5e-4)
+    with_grad(rs.StdConv2d(8, 16, kernel_size=3, stride=2, padding=1, bias=False), torch.randn(2, 8, 11, 9, generator=g), ref_stdconv)
+
+    # shape-level: the multi-output modules return what the reference returns
+    emb = vsm.Embeddings(cfg, img_size=64).to(DEV).train()
+    toks, feats = emb(torch.randn(2, 1, 64, 64, generator=g).to(DEV))
+    assert tuple(toks.shape) == (2, 16, hid) and [tuple(f.shape[2:]) for f in feats] == [(8, 8), (16, 16), (32, 32)]
+    tr = vsm.Transformer(cfg, 64, False).to(DEV).train()
+    enc, attn_w, feats = tr(torch.randn(2, 3, 64, 64, generator=g).to(DEV))
+    assert tuple(enc.shape) == (2, 16, hid) and attn_w == [] and len(feats) == 3
+    dec = vsm.DecoderCup(cfg).to(DEV).train()
+    y = dec(enc.detach(), [f.detach() for f in feats])
+    assert tuple(y.shape) == (2, cfg.decoder_channels[-1], 64, 64)
+    y.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in dec.parameters())

@@ -64,20 +64,22 @@ class _TapeFunction(torch.autograd.Function):
         return (None, None, None, *gin, *gpar)
 
 
-def _run_tape(module, inputs, build):
-    """Run `build(tape, *input_acts) -> Act` for `module`; returns an NCHW fp32 tensor."""
+def _run_tape(module, inputs, build, tape_cls=None, dtype=None):
+    """Run `build(tape, *input_acts) -> Act (or tuple of Acts)` for `module`; returns NCHW fp32 tensor(s).  `tape_cls`:
+    G.Tape (default) or umi.graph_tu.TUTape for the TransUNet blocks."""
     params = [p for p in module.parameters()]
-    dtype = module._umi_dtype()
+    dtype = dtype if dtype is not None else module._umi_dtype()
     N, _, H, W = inputs[0].shape
+    tape_cls = tape_cls or G.Tape
 
     uses_dropout = any(isinstance(m_, nn.Dropout) for m_ in module.modules())
     seed, seed_dev = G.dropout_seeds(module, inputs[0].device, module.training and uses_dropout)
 
     def run(record, in_needs):
-        tape = G.Tape(dtype, training=module.training, record=record,
-                      loss_scale=G.default_loss_scale(dtype, N * H * W),
-                      grad_sink=getattr(module, "_umi_grad_sink", None) if record else None,
-                      pack_cache=G.pack_cache_of(module), seed=seed, seed_dev=seed_dev)
+        tape = tape_cls(dtype, training=module.training, record=record,
+                        loss_scale=G.default_loss_scale(dtype, N * H * W),
+                        grad_sink=getattr(module, "_umi_grad_sink", None) if record else None,
+                        pack_cache=G.pack_cache_of(module), seed=seed, seed_dev=seed_dev)
         acts = [tape.input_nchw(x, needs_grad=need) for x, need in zip(inputs, in_needs)]
         out_act = build(tape, *acts)
         tape.finish_forward()

@@ -21,7 +21,7 @@ import torch.nn as nn
 from torch.nn import Conv2d, Dropout, LayerNorm, Linear
 from torch.nn.modules.utils import _pair
 
-from Model import _TapeFunction, _resolve_dtype
+from Model import _TapeFunction, _resolve_dtype, _run_tape
 from umi import graph as G
 from umi.graph_tu import TUTape
 
@@ -35,8 +35,26 @@ _JAX = dict(q="MultiHeadDotProductAttention_1/query", k="MultiHeadDotProductAtte
             fc0="MlpBlock_3/Dense_0", fc1="MlpBlock_3/Dense_1", ln0="LayerNorm_0", ln2="LayerNorm_2")
 
 
-def _no_standalone(name):
-    raise NotImplementedError(f"{name} runs inside VisionTransformer.forward (HIP tape); no standalone forward")
+# ---- standalone forwards of the sub-modules ---------------------------------------------------------------------------------
+# Inside VisionTransformer.forward the whole network is ONE tape.  Called on their own (as the reference's modules can be,
+# vit_seg_modeling.py:73-94,113-119,154-165,177-187,237-244,309-315,355-367) the sub-modules build a small tape of their own
+# through Model._run_tape: token tensors [B, N, C] travel as NCHW [B, C, 1, N] (the tape's token layout is NHWC with H = 1).
+def _sub_dtype(module):
+    return _resolve_dtype(getattr(module, "_compute_dtype", None))
+
+
+def _tok_in(x):
+    if x.dim() != 3:
+        raise ValueError(f"expected tokens [B, N, C], got {tuple(x.shape)}")
+    return x.permute(0, 2, 1).unsqueeze(2).contiguous()
+
+
+def _tok_out(y):
+    return y.squeeze(2).permute(0, 2, 1).contiguous()
+
+
+def _run_tokens(module, x, build):
+    return _tok_out(_run_tape(module, [_tok_in(x)], build, tape_cls=TUTape, dtype=_sub_dtype(module)))
 
 
 class Attention(nn.Module):
@@ -56,7 +74,8 @@ class Attention(nn.Module):
         self.proj_dropout = Dropout(config.transformer["attention_dropout_rate"])
 
     def forward(self, hidden_states):
-        _no_standalone("Attention")
+        """[B, N, C] -> (attention output, None): `vis` is always False here, the fused kernel never materialises the weights."""
+        return _run_tokens(self, hidden_states, lambda t, a: _build_attention(t, a, self)), None
 
 
 class Mlp(nn.Module):
@@ -76,7 +95,7 @@ class Mlp(nn.Module):
         nn.init.normal_(self.fc2.bias, std=1e-6)
 
     def forward(self, x):
-        _no_standalone("Mlp")
+        return _run_tokens(self, x, lambda t, a: _build_mlp(t, a, self))
 
 
 class Embeddings(nn.Module):
@@ -101,7 +120,15 @@ class Embeddings(nn.Module):
         self.dropout = Dropout(config.transformer["dropout_rate"])
 
     def forward(self, x):
-        _no_standalone("Embeddings")
+        """NCHW image -> (tokens [B, N, hidden], [skip features, deepest first]) (reference :154-165)."""
+        if x.size()[1] == 1:
+            x = x.repeat(1, 3, 1, 1)
+
+        def build(t, a):
+            h, skips = _build_embeddings(t, a, self)
+            return (h,) + tuple(skips)
+        outs = _run_tape(self, [x], build, tape_cls=TUTape, dtype=_sub_dtype(self))
+        return _tok_out(outs[0]), list(outs[1:])
 
 
 class Block(nn.Module):
@@ -116,7 +143,7 @@ class Block(nn.Module):
         self.attn = Attention(config, vis)
 
     def forward(self, x):
-        _no_standalone("Block")
+        return _run_tokens(self, x, lambda t, a: _build_block(t, a, self)), None
 
     def load_from(self, weights, n_block):
         root = f"Transformer/encoderblock_{n_block}"
@@ -148,7 +175,12 @@ class Encoder(nn.Module):
             self.layer.append(copy.deepcopy(Block(config, vis)))
 
     def forward(self, hidden_states):
-        _no_standalone("Encoder")
+        """[B, N, C] -> (encoded tokens, []) (reference :237-244; no attention maps: vis is False)."""
+        def build(t, h):
+            for blk in self.layer:
+                h = _build_block(t, h, blk)
+            return t.layer_norm(h, self.encoder_norm)
+        return _run_tokens(self, hidden_states, build), []
 
 
 class Transformer(nn.Module):
@@ -158,7 +190,18 @@ class Transformer(nn.Module):
         self.encoder = Encoder(config, vis)
 
     def forward(self, input_ids):
-        _no_standalone("Transformer")
+        """NCHW image -> (encoded tokens, [], skip features) (reference :253-256)."""
+        x = input_ids
+        if x.size()[1] == 1:
+            x = x.repeat(1, 3, 1, 1)
+
+        def build(t, a):
+            h, skips = _build_embeddings(t, a, self.embeddings)
+            for blk in self.encoder.layer:
+                h = _build_block(t, h, blk)
+            return (t.layer_norm(h, self.encoder.encoder_norm),) + tuple(skips)
+        outs = _run_tape(self, [x], build, tape_cls=TUTape, dtype=_sub_dtype(self))
+        return _tok_out(outs[0]), [], list(outs[1:])
 
 
 class Conv2dReLU(nn.Sequential):
@@ -179,7 +222,10 @@ class DecoderBlock(nn.Module):
         self.up = nn.UpsamplingBilinear2d(scale_factor=2)
 
     def forward(self, x, skip=None):
-        _no_standalone("DecoderBlock")
+        """NCHW [, NCHW skip at twice the size] -> NCHW (reference :309-315: bilinear x2, cat([x, skip]), two conv+BN+ReLU)."""
+        ins = [x] if skip is None else [x, skip]
+        return _run_tape(self, ins, lambda t, a, sk=None: _build_decoder_block(t, a, sk, self), tape_cls=TUTape,
+                         dtype=_sub_dtype(self))
 
 
 class SegmentationHead(nn.Sequential):
@@ -208,38 +254,62 @@ class DecoderCup(nn.Module):
         self.blocks = nn.ModuleList(DecoderBlock(i, o, s) for i, o, s in zip(in_channels, decoder_channels, skip_channels))
 
     def forward(self, hidden_states, features=None):
-        _no_standalone("DecoderCup")
+        """tokens [B, N, hidden] (N a square number) [, skip features] -> NCHW (reference :355-367)."""
+        B, n_tok, _ = hidden_states.shape
+        g = int(np.sqrt(n_tok))
+        feats = list(features) if features is not None else []
+        feats = feats[:self.config.n_skip]
+
+        def build(t, h, *sk):
+            return _build_decoder(t, h, list(sk) if sk else None, self, g, g)
+        return _run_tape(self, [_tok_in(hidden_states)] + feats, build, tape_cls=TUTape, dtype=_sub_dtype(self))
 
 
 # ---- tape builders -------------------------------------------------------------------------------------------------------
-def _build_block(t, h, blk: Block, cfg):
-    heads = cfg.transformer["num_heads"]
-    x = t.layer_norm(h, blk.attention_norm)
-    ctx = t.qkv_attention(x, blk.attn.query, blk.attn.key, blk.attn.value, heads)   # attn_dropout rate is 0.0 in every config
-    if cfg.transformer["attention_dropout_rate"] > 0 and t.training:
+def _build_attention(t, x, attn: Attention):
+    if attn.attn_dropout.p > 0 and t.training:
         raise NotImplementedError("attention-probability dropout > 0 is not supported (all reference configs use 0.0)")
-    a = t.linear(ctx, blk.attn.out.weight, blk.attn.out.bias)
+    ctx = t.qkv_attention(x, attn.query, attn.key, attn.value, attn.num_attention_heads)
+    return t.dropout(t.linear(ctx, attn.out.weight, attn.out.bias), attn.proj_dropout.p)
+
+
+def _build_mlp(t, x, mlp: Mlp):
+    x = t.dropout(t.gelu(t.linear(x, mlp.fc1.weight, mlp.fc1.bias)), mlp.dropout.p)
+    return t.dropout(t.linear(x, mlp.fc2.weight, mlp.fc2.bias), mlp.dropout.p)
+
+
+def _build_block(t, h, blk: Block, cfg=None):
+    """Pre-LN block (reference :177-187).  Rates and head count come from the modules themselves (== cfg.transformer[...])."""
+    a = _build_attention(t, t.layer_norm(h, blk.attention_norm), blk.attn)
     h = t.add(a, h)
-    x = t.layer_norm(h, blk.ffn_norm)
-    x = t.dropout(t.gelu(t.linear(x, blk.ffn.fc1.weight, blk.ffn.fc1.bias)), cfg.transformer["dropout_rate"])
-    x = t.dropout(t.linear(x, blk.ffn.fc2.weight, blk.ffn.fc2.bias), cfg.transformer["dropout_rate"])
+    x = _build_mlp(t, t.layer_norm(h, blk.ffn_norm), blk.ffn)
     return t.add(x, h)
+
+
+def _build_embeddings(t, a, emb: Embeddings):
+    feat, skips = build_resnet(t, a, emb.hybrid_model)
+    h = t.map_to_tokens(t.conv1x1_bias(feat, emb.patch_embeddings))
+    return t.dropout(t.add_position(h, emb.position_embeddings), emb.dropout.p), skips
+
+
+def _build_decoder_block(t, x, skip, blk: DecoderBlock):
+    N, H, W, C = x.shape
+    Cs = skip.shape[3] if skip is not None else 0
+    if skip is not None:
+        assert skip.shape[1:3] == (2 * H, 2 * W), f"skip {skip.shape} vs upsampled {(2 * H, 2 * W)}"
+    cat = t.alloc(N, 2 * H, 2 * W, C + Cs, device=x.raw.device)
+    up = t.bilinear2x_into(x, cat[..., :C])
+    xin = t.concat(cat, [up, t.copy_into(skip, cat[..., C:])]) if skip is not None else up
+    x = t.conv_bn(xin, blk.conv1[0].weight, blk.conv1[1])
+    return t.conv_bn(x, blk.conv2[0].weight, blk.conv2[1])
 
 
 def _build_decoder(t, tokens, features, dec: DecoderCup, gh, gw):
     x = t.tokens_to_map(tokens, gh, gw)
     x = t.conv_bn(x, dec.conv_more[0].weight, dec.conv_more[1])
     for i, blk in enumerate(dec.blocks):
-        skip = features[i] if (features is not None and i < dec.config.n_skip) else None
-        N, H, W, C = x.shape
-        Cs = skip.shape[3] if skip is not None else 0
-        if skip is not None:
-            assert skip.shape[1:3] == (2 * H, 2 * W), f"skip {skip.shape} vs upsampled {(2 * H, 2 * W)}"
-        cat = t.alloc(N, 2 * H, 2 * W, C + Cs, device=x.raw.device)
-        up = t.bilinear2x_into(x, cat[..., :C])
-        xin = t.concat(cat, [up, t.copy_into(skip, cat[..., C:])]) if skip is not None else up
-        x = t.conv_bn(xin, blk.conv1[0].weight, blk.conv1[1])
-        x = t.conv_bn(x, blk.conv2[0].weight, blk.conv2[1])
+        skip = features[i] if (features is not None and i < dec.config.n_skip and i < len(features)) else None
+        x = _build_decoder_block(t, x, skip, blk)
     return x
 
 
@@ -285,10 +355,9 @@ class VisionTransformer(nn.Module):
                           pack_cache=G.pack_cache_of(self))
             a = tape.input_nchw(x, needs_grad=False)
             emb = self.transformer.embeddings
-            feat, skips = build_resnet(tape, a, emb.hybrid_model)
-            gh, gw = feat.shape[1], feat.shape[2]
-            h = tape.map_to_tokens(tape.conv1x1_bias(feat, emb.patch_embeddings))
-            h = tape.dropout(tape.add_position(h, emb.position_embeddings), cfg.transformer["dropout_rate"])
+            h, skips = _build_embeddings(tape, a, emb)
+            gh = gw = int(np.sqrt(h.shape[2]))
+            assert gh * gw == h.shape[2]
             for blk in self.transformer.encoder.layer:
                 h = _build_block(tape, h, blk, cfg)
             h = tape.layer_norm(h, self.transformer.encoder.encoder_norm)

@@ -22,7 +22,8 @@ class StdConv2d(nn.Conv2d):
     container here: `TUTape.std_conv` runs umi_wstd_fwd + the conv kernels and their backward."""
 
     def forward(self, x):
-        raise NotImplementedError("StdConv2d runs inside VisionTransformer.forward (HIP tape); no standalone forward")
+        """Weight-standardised convolution on its own (reference :20-25): a one-op tape."""
+        return _run_block(self, [x], lambda t, a: t.std_conv(a, self))
 
 
 def conv3x3(cin, cout, stride=1, groups=1, bias=False):
@@ -53,7 +54,7 @@ class PreActBottleneck(nn.Module):
             self.gn_proj = nn.GroupNorm(cout, cout)          # one group per channel, default eps 1e-5 (reference :58)
 
     def forward(self, x):
-        raise NotImplementedError("PreActBottleneck runs inside VisionTransformer.forward (HIP tape)")
+        return _run_block(self, [x], lambda t, a: build_unit(t, a, self))
 
     def load_from(self, weights, n_block, n_unit):
         def get(name, conv=False):
@@ -94,7 +95,19 @@ class ResNetV2(nn.Module):
         ]))
 
     def forward(self, x):
-        raise NotImplementedError("ResNetV2 runs inside VisionTransformer.forward (HIP tape)")
+        """NCHW -> (1/16 feature, [skip 1/8, skip 1/4, skip 1/2]) (reference :142-160)."""
+        def build(t, a):
+            f, skips = build_resnet(t, a, self)
+            return (f,) + tuple(skips)
+        outs = _run_block(self, [x], build)
+        return outs[0], list(outs[1:])
+
+
+def _run_block(module, inputs, build):
+    """Standalone forward of a ResNet piece: its own small tape (the full network runs them on VisionTransformer's tape)."""
+    from Model import _resolve_dtype, _run_tape
+    from umi.graph_tu import TUTape
+    return _run_tape(module, inputs, build, tape_cls=TUTape, dtype=_resolve_dtype(getattr(module, "_compute_dtype", None)))
 
 
 # ---- tape builders ---------------------------------------------------------------------------------------------------
