@@ -250,8 +250,9 @@ def main():
         #          launches per step instead of ~350, but the 124 MB of gradients are reduced after the backward pass.
         # Which one is faster depends on the host (measured on this pool at N=1: eager 24.8 .. 31.7 ms, graph 23.9 .. 25.2 ms),
         # so "auto" times three steps of each during the warm-up and keeps the faster; every rank takes the same decision
-        # (MAX over ranks of each timing).  The graph is captured FIRST: on ROCm 7.2 an eager step between a graph's warm-up
-        # and its capture crashes hipStreamEndCapture.
+        # (MAX over ranks of each timing).  The graph is captured FIRST: a loss tensor kept from an eager step would hold
+        # that step's autograd graph alive and with it gradient accumulators bound to the default stream, which crashes
+        # hipStreamEndCapture (umi/graphs.py).
         from umi.graphs import GraphedStep
         trace = os.environ.get("UMI_BENCH_TRACE") == "1"
 

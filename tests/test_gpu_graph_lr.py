@@ -30,3 +30,10 @@ def test_trainer_single_on_hip_model_eager_and_graphed_follow_reference_run():
     """Product Trainer ('single', adaptive_lr) on the HIP U-Net, eager and graph=True, vs the reference's own run
     (tests/golden/trainer_single.npz): epoch losses, validation scores, iter_num, final learning rate, checkpoint files."""
     _run("trainer", "GRAPHED_TRAINER_OK")
+
+
+def test_capture_guard_refuses_live_eager_graph():
+    """Round 1's `hipStreamEndCapture` segfault: a tensor holding the autograd graph of an eager step keeps the parameters'
+    AccumulateGrad nodes bound to that step's stream (tools/experiments/exp_graph_accgrad.py reproduces crash and cure).
+    GraphedStep(optimizers=[...]) detects it and raises; after the tensor is detached the capture works."""
+    _run("guard", "GRAPH_GUARD_OK")

@@ -78,6 +78,34 @@ if what == "optim":
         print(kind, "ok", losses_g[-1], o_g.param_groups[0]["lr"])
     print("GRAPHED_SCHEDULE_OK")
 
+elif what == "guard":
+    # the capture guard: a live loss of an eager step must give a RuntimeError, not the hipStreamEndCapture segfault
+    L.CLASS_NUMBER = 2
+    torch.manual_seed(0)
+    m = Model.UNet(1, 2, 8, compute_dtype="fp16").to(DEV).train()
+    opt = uo.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    x = torch.randn(2, 1, 64, 64, device=DEV)
+    lab = torch.randint(0, 2, (2, 64, 64), device=DEV).float()
+
+    def step(xx, yy):
+        l = L.calc_loss(m(xx), yy, loss_type="dice_bce_mc")
+        opt.zero_grad(set_to_none=True)
+        l.backward()
+        opt.step()
+        return l
+    kept = step(x, lab)                       # eager step on the default stream, its graph stays referenced
+    torch.cuda.synchronize()
+    try:
+        GraphedStep(step, [x, lab], warmup=1, optimizers=[opt])
+        raise SystemExit("capture with a live eager-step graph was not refused")
+    except RuntimeError as e:
+        assert "gradient-accumulator" in str(e), e
+    kept = kept.detach()
+    gs = GraphedStep(step, [x, lab], warmup=1, optimizers=[opt])
+    l0 = float(gs(x, lab).detach())
+    assert l0 == l0
+    print("GRAPH_GUARD_OK", l0)
+
 elif what == "trainer":
     import tempfile
     from torch.utils.data import DataLoader, TensorDataset

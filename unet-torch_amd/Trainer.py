@@ -151,8 +151,8 @@ class Trainer():
         if gs is not None:
             outs = gs(*flat)
         else:
-            # first step of a batch shape (allocations, weight-pack caches) or a ragged batch: eager, on the side stream (an
-            # eager step on the default stream right before a capture crashes hipStreamEndCapture on ROCm 7.2)
+            # first step of a batch shape (allocations, weight-pack caches) or a ragged batch: eager, on the side stream; its
+            # outputs are detached, so no autograd graph of it survives into a later capture (umi/graphs.py)
             self._seen_shapes.add(key)
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):

@@ -7,8 +7,13 @@ and dispatch cost.  Measured on one MI355X: U-Net 25.7 -> 24.7 ms/step, TransUNe
 
 Rules that make the capture valid (the class enforces what it can):
   * static shapes and static input buffers: `GraphedStep.__call__(x, y)` copies the batch into the captured tensors;
-  * warm-up runs on a side stream and the capture follows IMMEDIATELY (an eager step on the default stream in between
-    leaves autograd state that crashes `hipStreamEndCapture` on ROCm 7.2);
+  * no tensor carrying the autograd graph of an EARLIER step may be alive at capture time (typically the loss an eager step
+    returned).  Cause of the `hipStreamEndCapture` segfault seen in round 1 (tools/experiments/exp_graph_accgrad.py reproduces
+    both orders): such a graph keeps the parameters' cached AccumulateGrad nodes alive, and those are bound to the stream of the
+    step that created them; the captured backward then accumulates the gradients on that non-capturing stream, a
+    cross-stream dependency the ROCm 7.2 runtime answers with a crash when the capture ends.  The warm-up here discards its
+    results, and with `optimizers=[...]` the constructor probes every parameter for such a surviving node and raises a
+    RuntimeError instead;
   * nothing in the step may synchronise with the host (`.item()`, prints of tensors): return tensors, read them later;
   * random streams must advance on the device: TransUNet's dropout kernels take their per-step offset from a device
     counter (`umi_dropout(seed_dev=...)`), so every replay draws fresh masks;
@@ -39,6 +44,7 @@ class GraphedStep:
         # a replay updates the parameters without passing through Python: their version counters must be bumped by hand or
         # version-keyed caches (ops.PackCache: the kernel-layout weight copies an eval-mode forward reuses) would go stale
         self._params = [p for opt in optimizers for g in opt.param_groups for p in g["params"]]
+        self._check_no_foreign_grad_accumulators(self._params)
         self.static_inputs = [t.clone() for t in example_inputs]
         # The graph refers to everything the step touched by ADDRESS: parameters, optimizer state (momentum buffers, the fused
         # optimizer's descriptor tables in pinned host memory), weight-pack caches.  Keep the closure -- and through it the
@@ -60,9 +66,35 @@ class GraphedStep:
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
             capture_error_mode = "thread_local" if multi else "global"
+        self._check_no_foreign_grad_accumulators(self._params)        # (the warm-up above discarded its outputs)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             self.static_outputs = step_fn(*self.static_inputs)
+
+    @staticmethod
+    def _check_no_foreign_grad_accumulators(params):
+        """A parameter's AccumulateGrad node is cached on the tensor (weakly) and bound to the stream it was created on.  If one
+        survives here, something outside holds the autograd graph of an earlier step (e.g. its loss tensor); capturing would
+        route the gradient accumulation through that step's stream and crash the runtime at the end of the capture.  Probe: tag
+        the node, drop our reference, fetch it again -- a node nobody else holds is rebuilt without the tag."""
+        import gc
+        token = object()
+        probed = []
+        for p in params:
+            if p.requires_grad and p.is_leaf:
+                acc = p.expand_as(p).grad_fn.next_functions[0][0]
+                acc.metadata["umi_capture_probe"] = token
+                probed.append(p)
+                del acc
+        gc.collect()
+        stale = [p for p in probed
+                 if p.expand_as(p).grad_fn.next_functions[0][0].metadata.get("umi_capture_probe") is token]
+        if stale:
+            raise RuntimeError(
+                f"GraphedStep: {len(stale)} parameter(s) still have the gradient-accumulator node of an earlier step "
+                "(a tensor with that step's autograd graph is alive, e.g. the loss it returned).  Capturing now would run the "
+                "gradient accumulation on that step's stream and crash hipStreamEndCapture; delete such tensors (or "
+                ".detach() what you keep) before building the GraphedStep.")
 
     def __call__(self, *inputs):
         for dst, src in zip(self.static_inputs, inputs):
