@@ -127,6 +127,14 @@ int umi_bn_bwd_apply(void* da, int ldda, const void* y, int ldy, const void* tx,
 int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, void* da, int ldda, const void* ybn, int ldybn,
                          const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
                          int dtype, umi_stream_t stream);
+
+/* Inference form of Conv2d(3, pad 1, bias=False) -> BatchNorm2d (running statistics) -> ReLU (reference Model.py:15-22 under
+ * model.eval(), the evaluation loop test_mc3serousv5.py:877-887): the layer's own transform out_tx[Co] = {mean, scale, shift,
+ * lo} is applied to the fp32 accumulators in the epilogue, y = max(scale * conv(tx(x), w) + shift, lo) is stored ACTIVATED
+ * and consumed without a transform; no statistics are produced.  fp16, matrix-core shapes only (UMI_ERR_UNSUPPORTED
+ * otherwise: use umi_conv_fwd + the consumer-side transform). */
+int umi_conv3x3_fwd_act(const void* x, int ldx, const void* tx, const void* wp8, const void* out_tx, void* y, int ldy,
+                        int N, int H, int W, int Ci, int Co, int dtype, umi_stream_t stream);
 /* The same fusion on the other producer of such a gradient: MaxPool2d(2) backward (reference Model.py:36) routes `dpool` into
  * `da` (accumulate != 0: adds to the skip-connection gradient already there) and, being the LAST contribution to `da`, also
  * emits stage 1 of the BatchNorm backward of the pooled layer (x = its raw output, tx / rstd its transform and 1/std):

@@ -593,6 +593,45 @@ def test_predict_mask_matches_reference_eval_argmax(golden_dir):
     assert torch.equal(mask, mask2) and vers == {k: e.ver for k, e in m._umi_pack_cache.ents.items()}
 
 
+@pytest.mark.parametrize("cls,cfg", [("UNet", (1, 2, 32)), ("UNet", (3, 4, 64)), ("UNet_attention", (1, 2, 32))])
+def test_eval_forward_with_bn_relu_on_store(monkeypatch, cls, cfg):
+    """SURVEY 8(f) rank 4 (reference evaluation loop test_mc3serousv5.py:877-887 over Model.py:7-26): in eval mode the fp16
+    path runs every matrix-core 3x3 convolution with its own BatchNorm (running statistics) + ReLU applied in the epilogue
+    (`umi_conv3x3_fwd_act`): tensors are stored activated, no statistics, no transform in the consumers.  Checked against the
+    same network with the epilogue switched off (UMI_NO_EVAL_FOLD=1: lazy consumer-side transform, the round-1 eval path)
+    and against the fp32 oracle: logits within 1e-2 of scale of both, argmax identical off near-ties."""
+    _need_gpu()
+    import Model
+    cin, ncls, feat = cfg
+    torch.manual_seed(5)
+    ref = getattr(ref_unet, {"UNet": "RefUNet", "UNet_attention": "RefUNetAttention"}[cls])(cin, ncls, feat, False)
+    ref.load_state_dict(recipe.fill_state_dict(ref.state_dict(), seed=50 + feat))
+    # non-trivial running statistics: a few training steps of the oracle
+    x, _ = recipe.synthetic_batch(2, cin, 64, 80, ncls, seed=50 + feat)
+    ref.train()
+    with torch.no_grad():
+        for _ in range(3):
+            ref(x + 0.1 * torch.randn_like(x))
+    ref.eval()
+    with torch.no_grad():
+        want = ref(x)
+    m = getattr(Model, cls)(cin, ncls, feat, False, compute_dtype="fp16")
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).eval()
+    with torch.no_grad():
+        monkeypatch.setenv("UMI_NO_EVAL_FOLD", "1")
+        lazy = m(x.to(DEV)).float().cpu()
+        monkeypatch.setenv("UMI_NO_EVAL_FOLD", "0")
+        fold = m(x.to(DEV)).float().cpu()
+    scale = want.abs().max().item()
+    assert (fold - lazy).abs().max().item() < 1e-2 * scale
+    assert (fold - want).abs().max().item() < 1e-2 * scale and (lazy - want).abs().max().item() < 1e-2 * scale
+    assert not torch.equal(fold, lazy) or feat < 16           # (the two paths round at different points)
+    top2 = torch.topk(want, 2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4e-2 * scale
+    assert safe.float().mean() > 0.5 and torch.equal(fold.argmax(1)[safe], want.argmax(1)[safe])
+
+
 def test_attention_dgrad_accumulate_is_bit_identical(monkeypatch):
     """Tensors with two consumers (attention gate: g and x) get their second gradient contribution added by the data-gradient
     kernel itself (UMI_CONV_ACCUMULATE); with the knob off the tape computes into a fresh tensor and adds.  Same bits."""

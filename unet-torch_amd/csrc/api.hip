@@ -134,6 +134,20 @@ extern "C" int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, v
     return umi_conv3x3_mfma_bnred(dy, lddy, wp8, da, ldda, ybn, ldybn, txbn, rstd, part, N, H, W, Ci, Co, (hipStream_t)stream);
 }
 
+int umi_conv3x3_mfma_act(const void* x, int ldx, const void* tx, const void* wp8, const void* out_tx, void* y, int ldy, int N,
+                         int H, int W, int Ci, int Co, hipStream_t s);
+
+// Inference form of conv3x3 + BatchNorm + ReLU (reference Model.py:15-22 under model.eval(), test_mc3serousv5.py:877-887):
+// y = max(out_tx.scale * conv(tx(x), w) + out_tx.shift, out_tx.lo) stored activated, no statistics.  UMI_ERR_UNSUPPORTED
+// when the shape is not on the matrix-core path (the caller then uses umi_conv_fwd and the consumer-side transform).
+extern "C" int umi_conv3x3_fwd_act(const void* x, int ldx, const void* tx, const void* wp8, const void* out_tx, void* y, int ldy,
+                                   int N, int H, int W, int Ci, int Co, int dtype, umi_stream_t stream) {
+    if (!x || !wp8 || !out_tx || !y || N <= 0 || H <= 0 || W <= 0 || ldx < Ci || ldy < Co) return UMI_ERR_BADARG;
+    if (!umi_conv3x3_mfma_ok(N, H, W, Ci, Co, 3, 3, 1, 1, H, W, ldx, ldy, dtype, dtype, 0, nullptr)) return UMI_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wp8 | (uintptr_t)out_tx) & 15) return UMI_ERR_BADARG;
+    return umi_conv3x3_mfma_act(x, ldx, tx, wp8, out_tx, y, ldy, N, H, W, Ci, Co, (hipStream_t)stream);
+}
+
 // stage 2 of the BatchNorm backward reduction on partial rows produced by umi_conv_dgrad_bnred
 int umi_colsum_rows_f16v(long M, int C);
 bool umi_bn_stats_f16v(const void* x, int ldx, float* part, long M, int C, hipStream_t s);

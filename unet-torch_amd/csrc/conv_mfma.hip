@@ -268,17 +268,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #endif
 
     // ---- epilogue: acc -> fp16 LDS tile [pixel][BN] ----------------------------------------------
+    // EPI 3 (inference): this conv's own BatchNorm (running statistics) + ReLU applied here, on the fp32 accumulators, so the
+    // tensor is stored ACTIVATED and its consumers load it as it is (no statistics, no transform on load)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int pix = (wm * 4 + nt) * 32 + lrow;
+        for (int g = 0; g < 4; ++g) {
+            const int co = wn * 64 + mt * 32 + g * 8 + lhalf * 4;
+            float4 ot[4];
+            if (EPI == 3) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+                for (int j = 0; j < 4; ++j)
+                    ot[j] = co + j < cvalid ? bn.tx[c0 + co + j] : make_float4(0.f, 1.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int pix = (wm * 4 + nt) * 32 + lrow;
                 half4 h;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (half_t)acc[mt][nt][g * 4 + j];
-                const int co = wn * 64 + mt * 32 + g * 8 + lhalf * 4;
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[mt][nt][g * 4 + j];
+                    if (EPI == 3) v = umi_tx(v, ot[j]);
+                    h[j] = (half_t)v;
+                }
                 *reinterpret_cast<half4*>(smem + pix * C::ERS + co * 2) = h;
             }
         }
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         }
     }
 
-    if (EPI) {
+    if (EPI == 1 || EPI == 2) {
         __syncthreads();                            // every thread is done with the tile: reuse it for the slice sums
         float* rs = reinterpret_cast<float*>(smem);         // [2][SL][BN]
 #pragma unroll
@@ -368,18 +380,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 
 template <int TH, int BN>
 int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H, int W,
-           int Ci, int Co, const BnRed* bnred, hipStream_t s) {
+           int Ci, int Co, const BnRed* bnred, hipStream_t s, const void* out_tx = nullptr) {
     const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = (Co + BN - 1) / BN;
     const long nblk = (long)N * tiles_x * tiles_y * n_co;
     dim3 grid((unsigned)nblk), block(256);
     static const bool xcd_off = [] { const char* e = getenv("UMI_CONV_NO_XCD_ORDER"); return e && e[0] == '1'; }();
     const int xcd_chunk = (n_co > 1 && !xcd_off) ? (int)(nblk / 8) : 0;     // ids beyond 8 * chunk (the remainder) keep their order
-    const BnRed bn = bnred ? *bnred : BnRed{nullptr, 0, nullptr, nullptr};
+    const BnRed bn = bnred ? *bnred : BnRed{nullptr, 0, (const float4*)out_tx, nullptr};
 #define GO(HT, EP)                                                                                               \
     hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, EP>), grid, block, 0, s, (const half_t*)x, ldx,          \
                        (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
                        tiles_y, n_co, xcd_chunk, bn)
-    if (bnred) { if (tx) GO(true, 2); else GO(false, 2); }
+    if (out_tx) { if (tx) GO(true, 3); else GO(false, 3); }
+    else if (bnred) { if (tx) GO(true, 2); else GO(false, 2); }
     else if (tx) { if (part) GO(true, 1); else GO(true, 0); }
     else    { if (part) GO(false, 1); else GO(false, 0); }
 #undef GO
@@ -474,4 +487,11 @@ int umi_conv3x3_mfma_bnred(const void* dy, int lddy, const void* wp8, void* da, 
     const BnRed bn{(const half_t*)ybn, ldybn, (const float4*)txbn, rstd};
     if (use_bn128(Co)) return launch<8, 128>(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, &bn, s);
     return launch<16, 64>(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, &bn, s);
+}
+
+// inference: conv + this layer's BatchNorm (running statistics) + ReLU on store (EPI 3); always the round-1 kernel
+int umi_conv3x3_mfma_act(const void* x, int ldx, const void* tx, const void* wp8, const void* out_tx, void* y, int ldy, int N,
+                         int H, int W, int Ci, int Co, hipStream_t s) {
+    if (use_bn128(Co)) return launch<8, 128>(x, ldx, tx, wp8, y, ldy, nullptr, N, H, W, Ci, Co, nullptr, s, out_tx);
+    return launch<16, 64>(x, ldx, tx, wp8, y, ldy, nullptr, N, H, W, Ci, Co, nullptr, s, out_tx);
 }

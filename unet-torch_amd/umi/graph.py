@@ -160,6 +160,17 @@ class Tape:
         if out is None:
             out = self.alloc(N, Ho, Wo, Co, device=a.raw.device)
         wf = weight.detach().float()
+        if (not self.training and not self.record and _eval_fold() and self.dtype == torch.float16 and (R, S, stride, pad) == (3, 3, 1, 1)
+                and ops.conv_plan(a.raw, out, 3, 3, 1, 1)[0] == 1):
+            # inference (reference test_mc3serousv5.py:877-887): BatchNorm from running statistics + ReLU applied by the conv's
+            # own epilogue, the tensor is stored activated -- no statistics pass, no transform in the consumers
+            tx, _ = ops.eval_bn_tx(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+            if bias is not None:
+                tx[:, 2] += tx[:, 1] * bias.detach().float()
+            if not relu:
+                tx[:, 3] = ops.NEG_INF
+            if ops.conv3x3_fwd_act(a.raw, a.tx, self._pack("conv_fwd", weight, wf, True), tx, out):
+                return Act(out, None)
         # the pointwise matrix-core kernel has no statistics epilogue: a 1x1 conv that feeds a BatchNorm (attention gates) runs
         # it without statistics and takes them in a separate HBM-bound pass over its (small: C_hidden channels) output; where
         # neither applies (odd channel counts) the generic kernel produces both
@@ -445,6 +456,8 @@ class Tape:
             parts.append((a, c0, c0 + C))
             c0 += C
         assert c0 == buf.shape[3]
+        if all(a.tx is None for a in acts):            # every part is stored activated (inference): nothing to apply on load
+            return Act(buf, None, parts=parts)
         return Act(buf, torch.cat(txs, 0).contiguous(), parts=parts)
 
     # ---- outputs -----------------------------------------------------------------------
@@ -478,6 +491,11 @@ class Tape:
         if self.loss_scale != 1.0:
             g = g / self.loss_scale
         return g.contiguous()
+
+
+def _eval_fold():
+    import os
+    return os.environ.get("UMI_NO_EVAL_FOLD") != "1"
 
 
 def dropout_seeds(module, device, training):

@@ -89,6 +89,8 @@ SIGNATURES = {
                              c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_bilinear2x": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_colsum": (c_int, [c_void_p, c_int, c_void_p, c_float, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umi_conv3x3_fwd_act": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_void_p]),
     "umi_conv_dgrad_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_bn_bwd_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -321,6 +321,19 @@ def conv_fwd(x, tx, wp, bias, y, R, S, stride, pad, want_stats=False, flags=0, u
     return part
 
 
+def conv3x3_fwd_act(x, tx, wp8, out_tx, y):
+    """Inference conv3x3 + this layer's BatchNorm/ReLU on store (y stored activated).  False when the shape is not on the
+    matrix-core path (nothing was launched)."""
+    N, H, W, Ci, ldx = _nhwc(x)
+    _, _, _, Co, ldy = _nhwc(y)
+    st = L.fn("umi_conv3x3_fwd_act")(x.data_ptr(), ldx, _ptr(tx), wp8.data_ptr(), out_tx.data_ptr(), y.data_ptr(), ldy,
+                                     N, H, W, Ci, Co, _dt(x), _stream())
+    if st == -2:
+        return False
+    L.check(st, "umi_conv3x3_fwd_act")
+    return True
+
+
 def bn_finalize(part, C, count, gamma, beta, eps, momentum, running_mean, running_var):
     rows = part.numel() // (2 * C)
     tx = torch.empty(C, 4, dtype=torch.float32, device=part.device)
