@@ -159,6 +159,16 @@ int umi_conv_wgrad(const void* x, int ldx, const void* txa, const void* dy, int 
                    float* dW, long s_co, long s_ci, long s_t, float out_scale,
                    int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
                    int Ho, int Wo, int dtype, int flags, void* ws, size_t ws_bytes, umi_stream_t stream);
+/* umi_conv_wgrad of a 3x3/stride-1/pad-1 conv fused with umi_bn_bwd_apply of the BatchNorm(+ReLU) that follows the conv
+ * (reference Model.py:14-21 DoubleConv backward: autograd runs cudnn_batch_norm_backward, then convolution_backward):
+ * `da` = gradient of the activated output (read only), `y`/`tx_bn`/`rstd`/`sum_dz`/`sum_dzx` as umi_bn_bwd_apply takes them;
+ * `dz` (a separate tensor) receives exactly what umi_bn_bwd_apply would have left in `da`, dW what umi_conv_wgrad would
+ * have produced from it.  UMI_ERR_UNSUPPORTED where the fused kernel does not apply (run the two calls instead). */
+int umi_conv_wgrad_bnapply(const void* x, int ldx, const void* txa, const void* da, int ldda, const void* y, int ldy,
+                           const void* tx_bn, const float* rstd, const float* sum_dz, const float* sum_dzx, void* dz,
+                           int lddz, float* dW, long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W,
+                           int Ci, int Co, int R, int S, int stride, int pad, int dtype, int flags, void* ws,
+                           size_t ws_bytes, umi_stream_t stream);
 
 /* Per-channel sum over pixels (bias gradients): out[c] = out_scale * sum_p x[p, c]. */
 size_t umi_colsum_ws_bytes(long M, int C);

@@ -486,3 +486,42 @@ def test_pool2_bwd_with_bn_reduction_matches_separate_kernels(shape, acc):
                                           ref[1].data_ptr(), M, C, lib.UMI_F16, ws.data_ptr(), ws.numel(), ops._stream()),
               "reduce")
     torch.testing.assert_close(sums.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 64, 64, 64), (1, 13, 37, 72, 136), (3, 8, 32, 128, 64), (1, 5, 70, 16, 24),
+                                   (2, 64, 64, 64, 128)])
+@pytest.mark.parametrize("strided", [False, True])
+def test_wgrad_with_bn_backward_apply_matches_separate_kernels(shape, strided):
+    """umi_conv_wgrad_bnapply (3x3 weight gradient whose producer waves also do stage 3 of the following BatchNorm's backward)
+    against umi_bn_bwd_apply + umi_conv_wgrad on the same inputs: the gradient of the raw conv output and the weight gradient
+    are both identical bit for bit (same expression, same rounding, same split-K order).  Ragged tiles (H % 4, W % 32, channel
+    counts that are not multiples of 64) and, with strided=True, operands that are channel slices of wider tensors."""
+    lib, ops = _gpu()
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+
+    def slab(c):                                       # [N,H,W,c] view, optionally a channel slice of a wider tensor
+        full = torch.randn(N, H, W, c + (16 if strided else 0), generator=g).half().to(DEV)
+        return full[..., 8:8 + c] if strided else full
+
+    x, y, da = slab(Ci), slab(Co), slab(Co)
+    da.mul_(0.1)
+    txa = _tx(Ci, g).to(DEV).contiguous()
+    tb = _tx(Co, g)
+    tb[:, 0] = 0.1 * torch.randn(Co, generator=g)
+    tb = tb.to(DEV).contiguous()
+    rstd = (0.5 + torch.rand(Co, generator=g)).to(DEV)
+    da_ref = da.clone()
+    s1, s2 = ops.bn_bwd(da_ref, y, tb, rstd)                       # in place: da_ref <- dz
+    gw_ref = torch.empty(Co, Ci, 3, 3, device=DEV)
+    ops.conv_wgrad(x, txa, da_ref, None, gw_ref, Ci * 9, 9, 1, 0.5, 3, 3, 1, 1)
+    keep = da.clone()
+    t1, t2 = ops.bn_bwd(da, y, tb, rstd, apply=False)
+    assert torch.equal(da, keep) and torch.equal(s1, t1) and torch.equal(s2, t2)
+    dz = torch.full((N, H, W, Co), float("nan"), device=DEV, dtype=torch.float16)
+    gw = torch.empty(Co, Ci, 3, 3, device=DEV)
+    assert ops.conv_wgrad_bnapply(x, txa, da, y, tb, rstd, t1, t2, dz, gw, Ci * 9, 9, 1, 0.5, 3, 3, 1, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(da, keep)                                   # the fused kernel only reads dA
+    assert torch.equal(dz, da_ref.contiguous())
+    assert torch.equal(gw, gw_ref)

@@ -84,6 +84,10 @@ int umi_wgrad_gather_mfma(const void* x, int ldx, const void* txa, const void* d
 bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
                           int ldx, int lddy, int dtype, int flags, const void* txb);
 size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co);
+int umi_wgrad3x3_mfma_bnapply(const void* x, int ldx, const void* txa, const void* da, int ldda, const void* ybn, int ldybn,
+                              const void* txbn, const float* rstd, const float* sum_dz, const float* sum_dzx, void* dz,
+                              int lddz, float* dW, long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci,
+                              int Co, void* ws, size_t ws_bytes, hipStream_t s);
 int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co,
                       long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws,
                       size_t ws_bytes, hipStream_t s);
@@ -293,6 +297,26 @@ extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co,
         if (m > g) g = m;
     }
     return g;
+}
+
+// Weight gradient of a 3x3 conv whose output feeds BatchNorm(+ReLU), fused with stage 3 of that BatchNorm's backward: the
+// gradient of the raw conv output, dz = gamma*rstd*(relu'(z)*dA - mean(dz) - xhat*mean(dz*xhat)) (umi_bn_bwd_apply's
+// expression, bit for bit), is formed while dA is staged for the matrix cores and written to `dz` once for the
+// data-gradient kernel.  `da` is left untouched.  UMI_ERR_UNSUPPORTED where the warp-specialised 3x3 kernel does not apply:
+// the caller then runs umi_bn_bwd_apply + umi_conv_wgrad.
+extern "C" int umi_conv_wgrad_bnapply(const void* x, int ldx, const void* txa, const void* da, int ldda, const void* y, int ldy,
+                                      const void* tx_bn, const float* rstd, const float* sum_dz, const float* sum_dzx,
+                                      void* dz, int lddz, float* dW, long s_co, long s_ci, long s_t, float out_scale, int N,
+                                      int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int dtype, int flags,
+                                      void* ws, size_t ws_bytes, umi_stream_t stream) {
+    if (!x || !da || !y || !tx_bn || !rstd || !sum_dz || !sum_dzx || !dz || !dW || !ws || N <= 0 || H <= 0 || W <= 0 ||
+        Ci <= 0 || Co <= 0 || ldx < Ci || ldda < Co || ldy < Co || lddz < Co || dz == da || dz == y)
+        return UMI_ERR_BADARG;
+    if (!umi_wgrad3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, H, W, ldx, ldda, dtype, flags, nullptr) || ldy % 8 || lddz % 8 ||
+        (long)H * W * (ldy > lddz ? ldy : lddz) * 2 >= 0x7FFFFFF0L)
+        return UMI_ERR_UNSUPPORTED;
+    return umi_wgrad3x3_mfma_bnapply(x, ldx, txa, da, ldda, y, ldy, tx_bn, rstd, sum_dz, sum_dzx, dz, lddz, dW, s_co, s_ci, s_t,
+                                     out_scale, N, H, W, Ci, Co, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int umi_conv_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, const void* txb,

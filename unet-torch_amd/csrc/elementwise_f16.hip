@@ -161,16 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v8(half_t* __restrict__ da, 
     for (long r = gt / G; r < M; r += stride_rows) {
         half8 yv = *reinterpret_cast<const half8*>(y + r * ldy + cg * 8);
         half8 gv = *reinterpret_cast<const half8*>(da + r * ldda + cg * 8);
-        half8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float yy = (float)yv[j];
-            float z = umi_tx_pre(yy, t[j]);
-            float dz = z > t[j].w ? (float)gv[j] : 0.f;
-            float xh = (yy - t[j].x) * rs[j];
-            o[j] = (half_t)(t[j].y * (dz - c1[j] - xh * c2[j]));
-        }
-        *reinterpret_cast<half8*>(da + r * ldda + cg * 8) = o;
+        *reinterpret_cast<half8*>(da + r * ldda + cg * 8) = umi_bn_dz8(yv, gv, t, rs, c1, c2);
     }
 }
 

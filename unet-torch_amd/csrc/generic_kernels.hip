@@ -499,14 +499,9 @@ __global__ void bn_bwd_apply_kernel(T* __restrict__ da, int ldda, const T* __res
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
         long r = i / C;
-        const float4 t = tx[c];
-        float yv = (float)y[r * ldy + c];
-        float g = (float)da[r * ldda + c];
-        float z = umi_tx_pre(yv, t);
-        float dz = z > t.w ? g : 0.f;
-        float xh = (yv - t.x) * rstd[c];
-        float dy = t.y * (dz - sum_dz[c] * invM - xh * sum_dzx[c] * invM);
-        da[r * ldda + c] = (T)dy;
+        // the same expression, term by term, as the vectorised kernel and the fused weight-gradient kernel (common.h)
+        da[r * ldda + c] = umi_bn_dz<T>((float)y[r * ldy + c], (float)da[r * ldda + c], tx[c], rstd[c], sum_dz[c] * invM,
+                                        sum_dzx[c] * invM);
     }
 }
 

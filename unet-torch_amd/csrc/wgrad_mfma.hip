@@ -278,11 +278,20 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_mfma_kernel(
 // kernel is not power-limited: 1.2 kW at 2.4 GHz).  One barrier per tile.  Same math, same partial-slab layout.
 constexpr int WS_SMEM = 2 * SMEM;        // 84,992 B (dynamic LDS)
 
-template <bool HAS_TX>
+// BNA: the dY operand is not read as stored but formed on the fly from the gradient of the ACTIVATED output (`dy` = dA) and the
+// layer's raw output y -- stage 3 of the BatchNorm + ReLU backward (elementwise_f16.hip bn_bwd_apply_v8, same expression, same
+// rounding to fp16) -- by the producer waves while they stage the tile; the workgroups of the first input-channel tile also
+// write it out (`dz`) for the data-gradient kernel.  Replaces a standalone pass that read y and dA and re-wrote dA in place.
+struct BnApply {
+    const half_t* y; int ldy; const float4* tx; const float* rstd; const float* sum_dz; const float* sum_dzx; long M;
+    half_t* dz; int lddz;
+};
+
+template <bool HAS_TX, bool BNA>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ dy, int lddy,
     float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x, int tiles_y, int tiles_total,
-    int tiles_per_split, int n_co_t, int fast_ci) {
+    int tiles_per_split, int n_co_t, int fast_ci, BnApply ba) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ws[];      // [2][SMEM] then txs[64]
     float4* txs = reinterpret_cast<float4*>(smem_ws + WS_SMEM);
     const int tid = threadIdx.x;
@@ -327,6 +336,27 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
         float4 t[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) t[j] = HAS_TX ? txs[j * 8 + sub] : make_float4(0.f, 1.f, 0.f, 0.f);
+        // BatchNorm-backward constants of this thread's 8 output channels (BNA)
+        float4 tb[8];
+        float rsb[8], c1[8], c2[8];
+        const long ybimg = BNA ? (long)H * W * ba.ldy : 0;
+        const int ybo0 = BNA ? (bcol * ba.ldy + co0 + sub * 8) * 2 : 0;
+        const bool dz_writer = BNA && ci0 == 0;
+        if (BNA) {
+            const float invM = 1.f / (float)ba.M;          // on the device, as the standalone kernels compute it
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = co0 + sub * 8 + j;
+                const bool in = c < Co;
+                tb[j] = in ? ba.tx[c] : make_float4(0.f, 1.f, 0.f, 0.f);
+                rsb[j] = in ? ba.rstd[c] : 0.f;
+                c1[j] = in ? ba.sum_dz[c] * invM : 0.f;
+                c2[j] = in ? ba.sum_dzx[c] * invM : 0.f;
+            }
+        }
+        half8 yraw0[KPB], yraw1[KPB];
+        bool bvalid0[KPB], bvalid1[KPB];
+        int st_n0 = 0, st_y0 = 0, st_x0 = 0, st_n1 = 0, st_y1 = 0, st_x1 = 0;      // tile origin of each register set (dz stores)
         // two register sets: the loads of tile i+2 stay in flight for a whole iteration while tile i+1 is transformed and
         // written (with a single set the producer's iteration is the exposed global-load latency plus the stores)
         half8 araw0[KPA], braw0[KPB], araw1[KPA], braw1[KPB];
@@ -360,7 +390,14 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
             const bool ok = b_on && nx_y + k < H && nx_x + bcol < W;                                            \
             braw##S[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                       \
                 yrs, UMI_EXP_LOAD_OK(ok) ? bbase + (unsigned)(boff0 + k * W * lddy * 2) : OOB, 0, 0));          \
+            if (BNA) {                                                                                          \
+                const __amdgpu_buffer_rsrc_t ybrs = __builtin_amdgcn_make_buffer_rsrc((void*)(ba.y + nx_n * ybimg), 0, (int)(ybimg * 2), 0x00020000); \
+                bvalid##S[k] = ok;                                                                              \
+                yraw##S[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                   \
+                    ybrs, ok ? (unsigned)org * (unsigned)(ba.ldy * 2) + (unsigned)(ybo0 + k * W * ba.ldy * 2) : OOB, 0, 0)); \
+            }                                                                                                   \
         }                                                                                                       \
+        if (BNA) { st_n##S = nx_n; st_y##S = nx_y; st_x##S = nx_x; }                                            \
         nx_x += 32;                                                                                             \
         if (nx_x >= W) { nx_x = 0; nx_y += TR; if (nx_y >= H) { nx_y = 0; ++nx_n; } }                           \
     } while (0)
@@ -382,6 +419,15 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
         }                                                                                                       \
         _Pragma("unroll") for (int k = 0; k < KPA; ++k)                                                         \
             if ((ptid >> 3) + 32 * k < HPIX) *reinterpret_cast<half8*>(sb + a_lds + k * 32 * PROW) = araw##S[k]; \
+        if (BNA) {                                                                                              \
+            _Pragma("unroll") for (int k = 0; k < KPB; ++k) {                                                   \
+                const half8 o = umi_bn_dz8(yraw##S[k], braw##S[k], tb, rsb, c1, c2);   /* as bn_bwd_apply_v8 (common.h) */ \
+                braw##S[k] = bvalid##S[k] ? o : braw##S[k];           /* pixels outside the image stay zero */   \
+                if (dz_writer && bvalid##S[k])                                                                  \
+                    *reinterpret_cast<half8*>(ba.dz + ((long)((long)st_n##S * H + st_y##S + k) * W + st_x##S + bcol) * ba.lddz + \
+                                              co0 + sub * 8) = braw##S[k];                                      \
+            }                                                                                                   \
+        }                                                                                                       \
         _Pragma("unroll") for (int k = 0; k < KPB; ++k) *reinterpret_cast<half8*>(sb + b_lds + k * 32 * PROW) = braw##S[k]; \
     } while (0)
 #endif
@@ -961,9 +1007,29 @@ size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co) {
     return (size_t)splits * 9 * Ci * Co * sizeof(float);
 }
 
+static int wgrad3x3_launch(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co,
+                           long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws,
+                           size_t ws_bytes, hipStream_t s, const BnApply* bna);
+
 int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co,
                       long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws,
                       size_t ws_bytes, hipStream_t s) {
+    return wgrad3x3_launch(x, ldx, txa, dy, lddy, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes, s, nullptr);
+}
+
+// weight gradient fused with stage 3 of the BatchNorm + ReLU backward of the conv's own output (see BnApply above)
+int umi_wgrad3x3_mfma_bnapply(const void* x, int ldx, const void* txa, const void* da, int ldda, const void* ybn, int ldybn,
+                              const void* txbn, const float* rstd, const float* sum_dz, const float* sum_dzx, void* dz,
+                              int lddz, float* dW, long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci,
+                              int Co, void* ws, size_t ws_bytes, hipStream_t s) {
+    const BnApply b{(const half_t*)ybn, ldybn, (const float4*)txbn, rstd, sum_dz, sum_dzx, (long)N * H * W,
+                    (half_t*)dz, lddz};
+    return wgrad3x3_launch(x, ldx, txa, da, ldda, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, ws, ws_bytes, s, &b);
+}
+
+static int wgrad3x3_launch(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co,
+                           long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws,
+                           size_t ws_bytes, hipStream_t s, const BnApply* bna) {
     int tiles_x, tiles_y, tiles_total, splits, tps;
     plan(N, H, W, Ci, Co, &tiles_x, &tiles_y, &tiles_total, &splits, &tps);
     if (ws_bytes < (size_t)splits * 9 * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
@@ -975,21 +1041,25 @@ int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, i
     static const int force_fast = [] { const char* e = getenv("UMI_WGRAD_FAST_CI"); return e ? atoi(e) : -1; }();
     const int fast_ci = force_fast >= 0 ? force_fast : (Co < 1.59 * Ci ? 1 : 0);
     static const bool classic = [] { const char* e = getenv("UMI_WGRAD_CLASSIC"); return e && e[0] == '1'; }();
+    if (bna && classic) return UMI_ERR_UNSUPPORTED;
     if (!classic) {
         constexpr int dyn = WS_SMEM + 64 * (int)sizeof(float4);
         static const int attr_rc = [] {
-            int a = (int)hipFuncSetAttribute((const void*)wgrad3x3_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-            int b = (int)hipFuncSetAttribute((const void*)wgrad3x3_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-            return a ? a : b;
+            int a = (int)hipFuncSetAttribute((const void*)wgrad3x3_ws_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            int b = (int)hipFuncSetAttribute((const void*)wgrad3x3_ws_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            int c = (int)hipFuncSetAttribute((const void*)wgrad3x3_ws_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            int d = (int)hipFuncSetAttribute((const void*)wgrad3x3_ws_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            return a ? a : (b ? b : (c ? c : d));
         }();
         if (attr_rc) return attr_rc;
         dim3 block_ws(512);
-        if (txa)
-            hipLaunchKernelGGL(wgrad3x3_ws_kernel<true>, grid, block_ws, dyn, s, (const half_t*)x, ldx, (const float4*)txa,
-                               (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t, fast_ci);
-        else
-            hipLaunchKernelGGL(wgrad3x3_ws_kernel<false>, grid, block_ws, dyn, s, (const half_t*)x, ldx, (const float4*)txa,
-                               (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t, fast_ci);
+        const BnApply ba = bna ? *bna : BnApply{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0};
+#define GO_WS(HT, BN_)                                                                                              \
+        hipLaunchKernelGGL((wgrad3x3_ws_kernel<HT, BN_>), grid, block_ws, dyn, s, (const half_t*)x, ldx, (const float4*)txa,   \
+                           (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_co_t, fast_ci, ba)
+        if (bna) { if (txa) GO_WS(true, true); else GO_WS(false, true); }
+        else { if (txa) GO_WS(true, false); else GO_WS(false, false); }
+#undef GO_WS
     } else if (txa)
         hipLaunchKernelGGL(wgrad3x3_mfma_kernel<true>, grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa,
                            (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, tiles_x, tiles_y, tiles_total, tps,

@@ -25,6 +25,15 @@ def _fuse_bnred():
     return os.environ.get("UMI_NO_BNRED_FUSION") != "1"          # tuning / A-B knob, read per call
 
 
+def _fuse_bnapply(Ci):
+    """Stage 3 of a conv's BatchNorm backward inside its weight-gradient kernel?  Every input-channel tile (64) of that kernel
+    repeats the elementwise work on the gradient tile it stages, so the fusion only pays with a single tile: measured per
+    layer at the bench shapes (tools/experiments/ab_bnapply.py, profiles/r02_wgrad_bnapply_ab.txt) -0.06..-0.09 ms at Ci = 64,
+    +0.03..+0.24 ms from Ci = 128 up.  UMI_BNAPPLY_FUSION=0 / all: never / wherever the kernel applies (A-B knob)."""
+    mode = os.environ.get("UMI_BNAPPLY_FUSION", "")
+    return mode != "0" and (Ci <= 64 or mode == "all")
+
+
 class Act:
     """Lazily-activated NHWC tensor.  `raw` is an [N,H,W,C] view, `tx` the consumer transform
     (None = consume as stored).  `grad` = d loss / d activated value (same layout/dtype)."""
@@ -212,7 +221,11 @@ class Tape:
                 inv = self.inv
                 # stage-1 rows from the producer of o.grad are only valid if nothing was added to o.grad after them
                 partials = o.bn_part if o.bn_part_at == o.gives else None
-                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd, partials=partials)   # o.grad <- d(raw conv output)
+                # 3x3 layers on the matrix-core weight-gradient kernel: stage 3 of the BatchNorm backward (the elementwise
+                # pass that turns o.grad into d(raw conv output)) is done by that kernel's producer waves
+                fuse = (_fuse_bnapply(Ci) and self.dtype == torch.float16 and (R, S, stride, pad) == (3, 3, 1, 1)
+                        and Ci % 8 == 0 and Co % 8 == 0)
+                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd, partials=partials, apply=not fuse)
                 o.bn_part = None
                 if self.grad_sink is None and inv != 1.0:
                     # un-scale all BatchNorm parameter gradients with one batched multiply at the end of the backward
@@ -224,7 +237,16 @@ class Tape:
                     self._set_pgrad(bn.weight, dgamma * inv)
                     self._set_pgrad(bn.bias, dbeta * inv)
                 gw = self._new_pgrad(weight)
-                ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad)
+                if fuse:
+                    dz = self.alloc(N, Ho, Wo, Co, device=out.device)
+                    if ops.conv_wgrad_bnapply(a.raw, a.tx, o.grad, out, tx, rstd, dbeta, dgamma, dz, gw, Ci * R * S, R * S, 1,
+                                              inv, R, S, stride, pad):
+                        o.grad = dz
+                    else:
+                        fuse = False
+                        ops.bn_bwd_apply(o.grad, out, tx, rstd, dbeta, dgamma)
+                if not fuse:
+                    ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad)
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)

@@ -62,6 +62,10 @@ SIGNATURES = {
                                c_long, c_long, c_long, c_float,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umi_conv_wgrad_bnapply": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_void_p, c_long, c_long, c_long, c_float,
+                                       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p, c_size_t, c_void_p]),
     "umi_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
     "umi_materialize_nchw": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_wstd_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

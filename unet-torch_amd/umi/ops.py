@@ -430,9 +430,10 @@ def conv_dgrad_bnred(dy, wp8, da, ybn, txbn, rstd):
     return part
 
 
-def bn_bwd(da, y, tx, rstd, partials=None):
+def bn_bwd(da, y, tx, rstd, partials=None, apply=True):
     """In place: da <- dy.  Returns (sum_dz, sum_dzx) = (d beta, d gamma) (still loss-scaled).  `partials`: stage-1 rows
-    already produced by conv_dgrad_bnred for this layer (the reduction pass over `da` is skipped)."""
+    already produced by conv_dgrad_bnred for this layer (the reduction pass over `da` is skipped).  apply=False: the sums
+    only, `da` stays the gradient of the activated output (conv_wgrad_bnapply does stage 3)."""
     N, H, W, C, ldy = _nhwc(y)
     _, _, _, _, ldda = _nhwc(da)
     M = N * H * W
@@ -446,10 +447,36 @@ def bn_bwd(da, y, tx, rstd, partials=None):
         L.check(L.fn("umi_bn_bwd_reduce")(da.data_ptr(), ldda, y.data_ptr(), ldy, tx.data_ptr(), rstd.data_ptr(),
                                           sums[0].data_ptr(), sums[1].data_ptr(), M, C, _dt(y), ws.data_ptr(),
                                           ws.numel(), _stream()), "umi_bn_bwd_reduce")
-    L.check(L.fn("umi_bn_bwd_apply")(da.data_ptr(), ldda, y.data_ptr(), ldy, tx.data_ptr(), rstd.data_ptr(),
-                                     sums[0].data_ptr(), sums[1].data_ptr(), M, C, _dt(y), _stream()),
-            "umi_bn_bwd_apply")
+    if apply:
+        bn_bwd_apply(da, y, tx, rstd, sums[0], sums[1])
     return sums[0], sums[1]
+
+
+def bn_bwd_apply(da, y, tx, rstd, sum_dz, sum_dzx):
+    N, H, W, C, ldy = _nhwc(y)
+    L.check(L.fn("umi_bn_bwd_apply")(da.data_ptr(), _nhwc(da)[4], y.data_ptr(), ldy, tx.data_ptr(), rstd.data_ptr(),
+                                     sum_dz.data_ptr(), sum_dzx.data_ptr(), N * H * W, C, _dt(y), _stream()),
+            "umi_bn_bwd_apply")
+
+
+def conv_wgrad_bnapply(x, txa, da, y, tx_bn, rstd, sum_dz, sum_dzx, dz, dW, s_co, s_ci, s_t, out_scale, R, S, stride, pad):
+    """Weight gradient fused with stage 3 of the following BatchNorm's backward (umi_conv_wgrad_bnapply); False where the
+    fused kernel does not apply (nothing was launched)."""
+    N, H, W, Ci, ldx = _nhwc(x)
+    _, Ho, Wo, Co, ldda = _nhwc(da)
+    if (Ho, Wo) != (H, W) or da.dtype != torch.float16:
+        return False
+    assert dW.dtype == torch.float32 and dW.is_contiguous() and dz.shape == da.shape
+    nb = L.fn("umi_conv_wgrad_ws_bytes")(N, Ho, Wo, Ci, Co, R, S, _dt(x), 0)
+    ws = workspace(nb, x.device)
+    st = L.fn("umi_conv_wgrad_bnapply")(x.data_ptr(), ldx, _ptr(txa), da.data_ptr(), ldda, y.data_ptr(), _nhwc(y)[4],
+                                        tx_bn.data_ptr(), rstd.data_ptr(), sum_dz.data_ptr(), sum_dzx.data_ptr(),
+                                        dz.data_ptr(), _nhwc(dz)[4], dW.data_ptr(), s_co, s_ci, s_t, out_scale,
+                                        N, H, W, Ci, Co, R, S, stride, pad, _dt(x), 0, ws.data_ptr(), ws.numel(), _stream())
+    if st == -2:                                   # UMI_ERR_UNSUPPORTED: not an error, the caller runs the two passes
+        return False
+    L.check(st, "umi_conv_wgrad_bnapply")
+    return True
 
 
 def conv_wgrad(x, txa, dy, txb, dW, s_co, s_ci, s_t, out_scale, R, S, stride, pad, flags=0):
