@@ -186,6 +186,20 @@ int umi_materialize_nchw(const void* x, int ldx, const void* tx, float* y_nchw,
  * biased variance, w_std = (w - mean) / sqrt(var + eps). fp32 parameters. */
 int umi_wstd_fwd(const float* w, float* wstd, float* rstd, int Co, int K, float eps, umi_stream_t stream);
 int umi_wstd_bwd(const float* wstd, const float* rstd, const float* g, float* dw, int Co, int K, umi_stream_t stream);
+/* The same for ALL StdConv2d layers of a model in one launch each way (a R50 hybrid has 52).  `descs`: DEVICE array sorted
+ * by blk0; an entry owns Co workgroups.  Backward: the gradient w.r.t. the standardised weights of entry i is read at
+ * g_base + off, the parameter gradient written at dw_base + off (flat per-step buffers, so the table never changes). */
+typedef struct umi_wstd_desc {
+    const float* w;
+    float* ws;
+    float* rstd;
+    long off;
+    int Co, K;
+    float eps;
+    int blk0;
+} umi_wstd_desc;
+int umi_wstd_fwd_multi(const void* descs, int n_desc, int total_rows, umi_stream_t stream);
+int umi_wstd_bwd_multi(const void* descs, int n_desc, int total_rows, const float* g_base, float* dw_base, umi_stream_t stream);
 
 /* GroupNorm (+ optional residual add, + optional ReLU) on NHWC, y = [relu](gn(x) [+ res]) (resnet_skip.py:47-58,68-73).
  * mean/rstd: [N*G] saved for backward.  Backward: dx (and dres = masked dy when dres != NULL), dgamma/dbeta scaled by
@@ -304,6 +318,8 @@ typedef struct umi_pack_desc {
     void* dst;
     long st, sk, sn;
     int T, K, N, flip_t, Kpad, Npad, k8, blk0;
+    int ldn, pad_;   /* ldn > Npad: the entry fills columns [0, Npad) of rows of length ldn (dst already offset to its first
+                        column): several source matrices packed side by side into one operand (Q/K/V projections); 0 = Npad */
 } umi_pack_desc;
 int umi_pack_block_elems(void);
 int umi_pack_kn_multi(const void* descs, int n_desc, int total_blocks, int dtype, umi_stream_t stream);

@@ -28,6 +28,7 @@ struct PackDesc {          // mirrors umi_pack_desc
     void* dst;
     long st, sk, sn;
     int T, K, N, flip_t, Kpad, Npad, k8, blk0;
+    int ldn, pad_;         // ldn: row length of the destination when this entry fills a column slice of a wider matrix (0 = Npad)
 };
 
 constexpr int OPT_BLOCK = 4096;      // elements per workgroup (256 threads x 4 x float4)
@@ -139,11 +140,13 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restr
     const long base = (long)(blk - d.blk0) * PACK_BLOCK;
     T* dst = (T*)d.dst;
     const int kb8 = d.Kpad >> 3;
+    const int ldn = d.ldn ? d.ldn : d.Npad;
 #pragma unroll 2
     for (int j = 0; j < PACK_BLOCK / 256; ++j) {
         const long i = base + j * 256 + threadIdx.x;
         if (i >= total) break;
         int n, k, t;
+        long o;                          // destination index (== i unless the entry is a column slice: ldn > Npad)
         if (d.k8) {                      // dst[t][k/8][n][k%8]
             const int k8 = (int)(i & 7);
             long r = i >> 3;
@@ -151,18 +154,20 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restr
             const int kb = (int)(r % kb8);
             t = (int)(r / kb8);
             k = kb * 8 + k8;
+            o = (((long)t * kb8 + kb) * ldn + n) * 8 + k8;
         } else {                         // dst[t][k][n]
             n = (int)(i % d.Npad);
             const long r = i / d.Npad;
             k = (int)(r % d.Kpad);
             t = (int)(r / d.Kpad);
+            o = ((long)t * d.Kpad + k) * ldn + n;
         }
         float v = 0.f;
         if (k < d.K && n < d.N) {
             const int ts = d.flip_t ? (d.T - 1 - t) : t;
             v = d.src[ts * d.st + k * d.sk + n * d.sn];
         }
-        dst[i] = (T)v;
+        dst[o] = (T)v;
     }
 }
 

@@ -66,6 +66,58 @@ __global__ __launch_bounds__(256) void wstd_bwd_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < K; i += 256) dw[(long)co * K + i] = r * (gp[i] - m1 - wh[i] * m2);
 }
 
+// All StdConv2d weights of a model in ONE launch each way (a R50 hybrid has 52 of them; one launch per conv costs more in
+// launch gaps than in work): workgroup = one output channel of one conv, found by binary search over the descriptor table.
+struct WstdDesc {          // mirrors umi_wstd_desc
+    const float* w;
+    float* ws;
+    float* rstd;
+    long off;              // element offset of this conv in the flat gradient buffers of the backward launch
+    int Co, K;
+    float eps;
+    int blk0;              // first workgroup (= output-channel row) of this conv
+};
+
+__device__ inline int wstd_find(const WstdDesc* d, int n, int blk) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void wstd_fwd_multi_kernel(const WstdDesc* __restrict__ descs, int n_desc) {
+    __shared__ float sh[16];
+    const WstdDesc d = descs[wstd_find(descs, n_desc, blockIdx.x)];
+    const int co = blockIdx.x - d.blk0, K = d.K;
+    const float* p = d.w + (long)co * K;                    // same arithmetic, in the same order, as wstd_fwd_kernel
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < K; i += 256) { float v = p[i]; s += v; q = fmaf(v, v, q); }
+    block_sum2(s, q, sh);
+    const float mean = s / K;
+    float var = q / K - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float r = rsqrtf(var + d.eps);
+    for (int i = threadIdx.x; i < K; i += 256) d.ws[(long)co * K + i] = (p[i] - mean) * r;
+    if (threadIdx.x == 0) d.rstd[co] = r;
+}
+
+__global__ __launch_bounds__(256) void wstd_bwd_multi_kernel(const WstdDesc* __restrict__ descs, int n_desc,
+                                                             const float* __restrict__ g_base, float* __restrict__ dw_base) {
+    __shared__ float sh[16];
+    const WstdDesc d = descs[wstd_find(descs, n_desc, blockIdx.x)];
+    const int co = blockIdx.x - d.blk0, K = d.K;
+    const float* wh = d.ws + (long)co * K;
+    const float* gp = g_base + d.off + (long)co * K;
+    float* dw = dw_base + d.off + (long)co * K;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < K; i += 256) { float gv = gp[i]; s += gv; q = fmaf(gv, wh[i], q); }
+    block_sum2(s, q, sh);
+    const float m1 = s / K, m2 = q / K, r = d.rstd[co];
+    for (int i = threadIdx.x; i < K; i += 256) dw[i] = r * (gp[i] - m1 - wh[i] * m2);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm on NHWC: statistics per (sample, group); group = Cg contiguous channels.
 template <typename T>
@@ -589,6 +641,21 @@ extern "C" int umi_wstd_fwd(const float* w, float* wstd, float* rstd, int Co, in
 extern "C" int umi_wstd_bwd(const float* wstd, const float* rstd, const float* g, float* dw, int Co, int K, umi_stream_t st) {
     if (!wstd || !rstd || !g || !dw || Co <= 0 || K <= 0) return UMI_ERR_BADARG;
     hipLaunchKernelGGL(wstd_bwd_kernel, dim3(Co), dim3(256), 0, (hipStream_t)st, wstd, rstd, g, dw, K);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+extern "C" int umi_wstd_fwd_multi(const void* descs, int n_desc, int total_rows, umi_stream_t st) {
+    if (!descs || n_desc <= 0 || total_rows <= 0) return UMI_ERR_BADARG;
+    hipLaunchKernelGGL(wstd_fwd_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)st, (const WstdDesc*)descs, n_desc);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+extern "C" int umi_wstd_bwd_multi(const void* descs, int n_desc, int total_rows, const float* g_base, float* dw_base,
+                                  umi_stream_t st) {
+    if (!descs || !g_base || !dw_base || n_desc <= 0 || total_rows <= 0) return UMI_ERR_BADARG;
+    hipLaunchKernelGGL(wstd_bwd_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)st, (const WstdDesc*)descs, n_desc,
+                       g_base, dw_base);
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }

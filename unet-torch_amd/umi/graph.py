@@ -500,11 +500,15 @@ class Tape:
         for step in reversed(self.steps):
             step()
         self.steps = []
+        self._finish_param_grads()
         if self._deferred_unscale:
             torch._foreach_mul_(self._deferred_unscale, self.inv)
             self._deferred_unscale = []
         if self.grad_sink is not None:
             self.grad_sink.finish()
+
+    def _finish_param_grads(self):
+        """Hook: parameter-gradient work batched at the end of the backward pass (TUTape: StdConv2d standardisation)."""
 
     def input_grad_nchw(self, a: Act):
         if a.grad is None:

@@ -20,6 +20,7 @@ class TUTape(Tape):
         self._seed = int(seed)
         self._seed_dev = seed_dev         # int32 device scalar mixed into every dropout seed inside the kernel: a step replayed
         self._drop_count = 0              # from a captured HIP graph (host-side `seed` frozen) still draws fresh masks
+        self._wstd_pending, self._wstd_flat = [], None
 
     # gradients of a value with several consumers are summed by a libunetmi kernel (no torch arithmetic)
     def _give(self, act, g):
@@ -38,27 +39,63 @@ class TUTape(Tape):
         assert Ca == Ci
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         out = self.alloc(N, Ho, Wo, Co, device=a.raw.device)
-        ws, rstd = ops_tu.wstd_fwd(w, 1e-5)
-        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(ws, self.dtype, k8=bool(lay)), None, out, R, S, stride, pad)
+        c = self.pack_cache
+        ent = None
+        if c is not None and isinstance(w, torch.nn.Parameter) and w.dtype == torch.float32 and w.is_contiguous():
+            # standardised weights and their kernel layouts come from the model's cache: refreshed for all 52 convs of the
+            # hybrid by two launches at the start of the step (PackCache.refresh) instead of three launches per conv
+            ent = c.wstd(w, 1e-5)
+            ws, rstd = ent.ws, ent.rstd
+
+            def packed(kind):
+                return lambda lay: c.get(kind, ws, self.dtype, bool(lay))
+        else:
+            ws, rstd = ops_tu.wstd_fwd(w, 1e-5)
+
+            def packed(kind):
+                return lambda lay: ops.PACKERS[kind](ws, self.dtype, k8=bool(lay))
+        ops.conv_fwd(a.raw, a.tx, packed("conv_fwd"), None, out, R, S, stride, pad)
         o = Act(out, None)
         if self.record:
             def bwd():
                 if o.grad is None:
                     return
-                gws = torch.empty_like(ws)
+                slot = self._wstd_slot(ent, w) if ent is not None else None
+                gws = slot[0] if slot is not None else torch.empty_like(ws)
                 ops.conv_wgrad(a.raw, a.tx, o.grad, None, gws, Ci * R * S, R * S, 1, self.inv, R, S, stride, pad)
-                self._set_pgrad(w, ops_tu.wstd_bwd(ws, rstd, gws))
+                # with a slot the standardisation's backward runs once for all convs at the end of the backward pass
+                self._set_pgrad(w, slot[1] if slot is not None else ops_tu.wstd_bwd(ws, rstd, gws))
                 if _wants_grad(a):
                     dx = self.alloc(N, H, W, Ci, device=out.device)
                     if stride == 1:
-                        ops.conv_fwd(o.grad, None, lambda lay: ops.pack_conv_dgrad(ws, self.dtype, k8=bool(lay)), None, dx,
-                                     R, S, 1, R - 1 - pad)
+                        ops.conv_fwd(o.grad, None, packed("conv_dgrad"), None, dx, R, S, 1, R - 1 - pad)
                     else:
-                        self._strided_dgrad(o.grad, lambda lay: ops_tu.pack_conv_dgrad_strided(ws, self.dtype, k8=bool(lay)),
-                                            dx, R, S, stride, pad)
+                        self._strided_dgrad(o.grad, packed("conv_dgrad_strided"), dx, R, S, stride, pad)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o
+
+    def _wstd_slot(self, ent, w):
+        """(gradient w.r.t. the standardised weight, parameter gradient) views of this conv in two flat per-step buffers; the
+        second is filled by ONE umi_wstd_bwd_multi launch when the backward pass ends.  None where that deferral is not safe:
+        a gradient sink wants its own buffers filled as the pass proceeds, and a weight used twice accumulates at once."""
+        if self.grad_sink is not None or id(w) in self.param_grads or any(e is ent for e in self._wstd_pending):
+            return None
+        if self._wstd_flat is None:
+            n = self.pack_cache.wstd_total
+            self._wstd_flat = (torch.empty(n, dtype=torch.float32, device=w.device),
+                               torch.empty(n, dtype=torch.float32, device=w.device))
+        self._wstd_pending.append(ent)
+        return tuple(f[ent.off:ent.off + w.numel()].view(w.shape) for f in self._wstd_flat)
+
+    def backward(self):
+        self._wstd_pending, self._wstd_flat = [], None
+        super().backward()
+
+    def _finish_param_grads(self):
+        if self._wstd_pending:
+            self.pack_cache.wstd_bwd(self._wstd_pending, *self._wstd_flat)
+            self._wstd_pending = []
 
     @staticmethod
     def _strided_dgrad(dy, wpd, dx, R, S, stride, pad):
@@ -269,10 +306,24 @@ class TUTape(Tape):
         The modules stay separate `nn.Linear`s (reference state_dict keys); their weights are concatenated per step."""
         N, H, W, C = a.shape
         mods = (query, key, value)
-        wcat = torch.cat([m.weight.detach().float() for m in mods], 0).reshape(3 * C, C, 1, 1)
-        bcat = torch.cat([m.bias.detach().float() for m in mods], 0)
+        c = self.pack_cache
+        if c is not None and all(isinstance(t_, torch.nn.Parameter) and t_.dtype == torch.float32 and t_.is_contiguous()
+                                 for m in mods for t_ in (m.weight, m.bias)):
+            # the concatenated operands live in the model's cache, each projection packed into its slice by the step's one
+            # pack launch (no torch.cat, no per-layer pack launches)
+            wts = [m.weight for m in mods]
+            bcat = c.get_cat("bias", [m.bias for m in mods], torch.float32, False)
+
+            def packed(kind):
+                return lambda lay: c.get_cat(kind, wts, self.dtype, bool(lay))
+        else:
+            wcat = torch.cat([m.weight.detach().float() for m in mods], 0).reshape(3 * C, C, 1, 1)
+            bcat = torch.cat([m.bias.detach().float() for m in mods], 0)
+
+            def packed(kind):
+                return lambda lay: ops.PACKERS[kind](wcat, self.dtype, k8=bool(lay))
         qkv = self.alloc(N, H, W, 3 * C, device=a.raw.device)
-        ops.conv_fwd(a.raw, a.tx, lambda lay: ops.pack_conv_fwd(wcat, self.dtype, k8=bool(lay)), bcat, qkv, 1, 1, 1, 0)
+        ops.conv_fwd(a.raw, a.tx, packed("conv_fwd"), bcat, qkv, 1, 1, 1, 0)
         q, k, v = (qkv[..., i * C:(i + 1) * C] for i in range(3))
         out = self.alloc(N, H, W, C, device=a.raw.device)
         lse = ops_tu.attn_fwd(q, k, v, out, heads)
@@ -292,7 +343,7 @@ class TUTape(Tape):
                     self._set_pgrad(m.bias, gb[i * C:(i + 1) * C])
                 if _wants_grad(a):
                     dx = self.alloc(N, H, W, C, device=out.device)
-                    ops.conv_fwd(dqkv, None, lambda lay: ops.pack_conv_dgrad(wcat, self.dtype, k8=bool(lay)), None, dx, 1, 1, 1, 0)
+                    ops.conv_fwd(dqkv, None, packed("conv_dgrad"), None, dx, 1, 1, 1, 0)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o

@@ -70,6 +70,8 @@ SIGNATURES = {
     "umi_materialize_nchw": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_wstd_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "umi_wstd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "umi_wstd_fwd_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "umi_wstd_bwd_multi": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "umi_gn_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                            c_int, c_long, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "umi_gn_fwd_ws_bytes": (c_size_t, [c_int, c_long, c_int]),

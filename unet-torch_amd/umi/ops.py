@@ -119,7 +119,7 @@ def pack_convT_dgrad(w: torch.Tensor, dtype, k8=False):
 
 
 def _pack_args(kind, shape):
-    """(T, K, N, st, sk, sn, flip_t) of the four weight packings above."""
+    """(T, K, N, st, sk, sn, flip_t) of the weight packings above."""
     if len(shape) == 2:                              # nn.Linear weight [Co, Ci] = a 1x1 convolution
         shape = (shape[0], shape[1], 1, 1)
     if kind == "conv_fwd":
@@ -128,6 +128,11 @@ def _pack_args(kind, shape):
     if kind == "conv_dgrad":
         Co, Ci, R, S = shape
         return R * S, Co, Ci, 1, Ci * R * S, R * S, 1
+    if kind == "conv_dgrad_strided":                 # [R*S][Co][Ci], taps not flipped (UMI_CONV_DGRAD_STRIDED)
+        Co, Ci, R, S = shape
+        return R * S, Co, Ci, 1, Ci * R * S, R * S, 0
+    if kind == "bias":                               # a vector as a 1 x C matrix (get_cat: biases end to end)
+        return 1, 1, shape[0], 0, 0, 1, 0
     if kind == "convT_fwd":
         Cin, Cout = shape[:2]
         return 4, Cin, Cout, 1, Cout * 4, 4, 0
@@ -137,8 +142,14 @@ def _pack_args(kind, shape):
     raise KeyError(kind)
 
 
+def pack_conv_dgrad_strided(w, dtype, k8=False):
+    """OIHW -> [R*S][Co][Ci] unflipped, for UMI_CONV_DGRAD_STRIDED (k8: the MFMA kernels' [R*S][Co/8][Ci][8])."""
+    Co, Ci, R, S = w.shape
+    return pack_kn(w, R * S, Co, Ci, 1, Ci * R * S, R * S, False, dtype, k8=k8)
+
+
 PACKERS = {"conv_fwd": pack_conv_fwd, "conv_dgrad": pack_conv_dgrad, "convT_fwd": pack_convT_fwd,
-           "convT_dgrad": pack_convT_dgrad}
+           "convT_dgrad": pack_convT_dgrad, "conv_dgrad_strided": pack_conv_dgrad_strided}
 
 
 class PackCache:
@@ -146,16 +157,29 @@ class PackCache:
 
     The copies are caches of the fp32 OIHW masters (never serialised).  An entry is valid while the parameter's
     `_version` and storage are unchanged, so inference loops pack once; after an optimizer step every entry is stale and
-    `refresh()` re-packs all of them with ONE umi_pack_kn_multi launch (a U-Net has 45 such packings per step)."""
+    `refresh()` re-packs all of them with ONE umi_pack_kn_multi launch (a U-Net has 45 such packings per step).
+
+    Two kinds of derived operands live here too (TransUNet):
+      * `wstd(w)`: the standardised copy of a StdConv2d weight (resnet_skip.py:20-23) and its per-channel rstd, persistent
+        tensors recomputed for ALL such convs by one umi_wstd_fwd_multi launch in `refresh()`; their kernel layouts are
+        ordinary entries keyed on the standardised tensor, so they ride in the same pack launch;
+      * `get_cat(kind, [w...])`: several matrices packed side by side into ONE operand (the Q/K/V projections run as one
+        GEMM): one entry per source, each filling its slice of a shared destination."""
 
     class _Ent:
-        __slots__ = ("w", "args", "dst", "ver", "k8")
+        __slots__ = ("w", "args", "dst", "ver", "k8", "ptr", "ldn")
+
+    class _Wstd:
+        __slots__ = ("w", "ws", "rstd", "eps", "ver", "off")
 
     def __init__(self):
         self.ents = {}
+        self.cats = {}
+        self.wstds = {}
+        self.wstd_total = 0        # elements of all registered StdConv2d weights (size of the backward's flat buffers)
         self._tables = {}          # tuple(entry keys) -> (device address of the descriptor table, total_blocks, n)
 
-    _CAP = 1 << 18                     # bytes of descriptor-table space (a U-Net's table is 3 KB)
+    _CAP = 1 << 18                     # bytes of descriptor-table space (a U-Net's table is 3 KB, a TransUNet's 20 KB)
 
     def _buffers(self):
         """Pinned staging + device space for the descriptor tables, allocated once and OUTSIDE any HIP-graph capture (the
@@ -197,21 +221,25 @@ class PackCache:
     def _ver(w):
         return (w._version, w.data_ptr())
 
-    def get(self, kind, w, dtype, k8):
+    def _new_ent(self, kind, w, k8, dst, ptr, ldn):
         import weakref
+        e = PackCache._Ent()
+        e.w, e.args, e.k8, e.ver = weakref.ref(w), _pack_args(kind, w.shape), bool(k8), None
+        e.dst, e.ptr, e.ldn = dst, ptr, ldn
+        if not torch.cuda.is_current_stream_capturing():
+            self._buffers()
+        # (tables built for the previous entry set stay where they are: a captured graph may still replay them)
+        return e
+
+    def get(self, kind, w, dtype, k8):
         key = (id(w), kind, dtype, bool(k8))
         e = self.ents.get(key)
         if e is not None and e.w() is not w:
             e = None                                   # id() reused by another tensor
         if e is None:
-            e = PackCache._Ent()
-            e.w, e.args, e.k8, e.ver = weakref.ref(w), _pack_args(kind, w.shape), bool(k8), None
-            T, K, N = e.args[:3]
-            e.dst = torch.empty(T * K * N, dtype=dtype, device=w.device)
-            self.ents[key] = e
-            if not torch.cuda.is_current_stream_capturing():
-                self._buffers()
-            # (tables built for the previous entry set stay where they are: a captured graph may still replay them)
+            T, K, N = _pack_args(kind, w.shape)[:3]
+            dst = torch.empty(T * K * N, dtype=dtype, device=w.device)
+            e = self.ents[key] = self._new_ent(kind, w, k8, dst, dst.data_ptr(), 0)
         ver = self._ver(w)
         if e.ver != ver:
             T, K, N, st, sk, sn, flip = e.args
@@ -221,51 +249,157 @@ class PackCache:
             e.ver = ver
         return e.dst
 
-    def refresh(self):
-        """Re-pack every stale entry (one launch per storage dtype)."""
+    def get_cat(self, kind, ws, dtype, k8):
+        """One packed operand from several source matrices: "conv_fwd" concatenates along the output channels (columns of the
+        GEMM's B operand), "conv_dgrad" along its rows, "bias" 1-D vectors end to end.  1x1 / Linear weights only."""
+        key = (tuple(id(w) for w in ws), kind, dtype, bool(k8))
+        c = self.cats.get(key)
+        if c is not None and any(e.w() is not w for e, w in zip(c[1], ws)):
+            c = None
+        if c is None:
+            args = [_pack_args(kind, w.shape) for w in ws]
+            assert all(a[0] == 1 for a in args), "get_cat packs single-tap (1x1 / Linear) weights"
+            esz = torch.empty(0, dtype=dtype).element_size()
+            if kind == "conv_dgrad":                                   # [Ktot(/8)][N]([8]): row blocks, one after the other
+                assert len({a[2] for a in args}) == 1 and (not k8 or all(a[1] % 8 == 0 for a in args))
+                offs, tot, ldn = [], 0, 0
+                for a in args:
+                    offs.append(tot)
+                    tot += a[1] * a[2]
+            else:                                                      # [K(/8)][Ntot]([8]): column slices of rows of length Ntot
+                assert len({a[1] for a in args}) == 1
+                ntot = sum(a[2] for a in args)
+                offs, n0 = [], 0
+                for a in args:
+                    offs.append(n0 * (8 if k8 else 1))
+                    n0 += a[2]
+                tot, ldn = args[0][1] * ntot, ntot
+            dst = torch.empty(tot, dtype=dtype, device=ws[0].device)
+            ents = []
+            for w, off in zip(ws, offs):
+                e = self._new_ent(kind, w, k8, dst, dst.data_ptr() + off * esz, ldn)
+                self.ents[(id(w), kind + "@cat", dtype, bool(k8), id(dst))] = e
+                ents.append(e)
+            c = self.cats[key] = (dst, ents)
+        stale = [(None, e, w) for e, w in zip(c[1], ws) if e.ver != self._ver(w)]
+        if stale:
+            self._repack(stale)
+        return c[0]
+
+    def wstd(self, w, eps):
+        """The persistent (standardised weight, rstd) pair of a StdConv2d parameter; current when `refresh()` ran after the
+        last change of `w` (else recomputed here, by the single-conv kernel)."""
+        import weakref
+        e = self.wstds.get(id(w))
+        if e is not None and e.w() is not w:
+            e = None
+        ver = self._ver(w)
+        if e is None:
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            e = self.wstds[id(w)] = PackCache._Wstd()
+            e.w, e.eps, e.ver, e.off = weakref.ref(w), float(eps), None, self.wstd_total
+            e.ws = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+            e.rstd = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
+            self.wstd_total += (w.numel() + 63) // 64 * 64         # 256-byte aligned slots
+        if e.ver != ver:
+            L.check(L.fn("umi_wstd_fwd")(w.data_ptr(), e.ws.data_ptr(), e.rstd.data_ptr(), w.shape[0], w[0].numel(), e.eps,
+                                         _stream()), "umi_wstd_fwd")
+            torch.autograd.graph.increment_version(e.ws)           # its packed copies are stale now
+            e.ver = ver
+        return e
+
+    def _wstd_table(self, ents):
         import numpy as np
+        tkey = ("wstd",) + tuple((id(e), e.w().data_ptr()) for e in ents)
+        tab = self._tables.get(tkey)
+        if tab is None:
+            arr = np.zeros(len(ents), dtype=_WSTD_DESC)
+            b0 = 0
+            for i, e in enumerate(ents):
+                w = e.w()
+                arr[i] = (w.data_ptr(), e.ws.data_ptr(), e.rstd.data_ptr(), e.off, w.shape[0], w[0].numel(), e.eps, b0)
+                b0 += w.shape[0]
+            tab = self._tables[tkey] = (self._upload(arr), b0, len(ents))
+        return tab
+
+    def wstd_bwd(self, ents, g_flat, dw_flat):
+        """dw_flat[e.off:...] <- backward of the standardisation for every entry, from the gradients w.r.t. the standardised
+        weights in g_flat (same offsets): one launch."""
+        dev_ptr, rows, n = self._wstd_table(ents)
+        L.check(L.fn("umi_wstd_bwd_multi")(dev_ptr, n, rows, g_flat.data_ptr(), dw_flat.data_ptr(), _stream()),
+                "umi_wstd_bwd_multi")
+
+    def _repack(self, items):
+        """items: [(key, entry, source tensor)] -> one umi_pack_kn_multi launch per storage dtype."""
+        import numpy as np
+        by_dtype = {}
+        for it in items:
+            by_dtype.setdefault(it[1].dst.dtype, []).append(it)
+        blk = None
+        for dtype, its in by_dtype.items():
+            tkey = tuple((id(e), w.data_ptr()) for _, e, w in its)
+            tab = self._tables.get(tkey)
+            if tab is None:
+                blk = blk or L.fn("umi_pack_block_elems")()
+                arr = np.zeros(len(its), dtype=_PACK_DESC)
+                b0 = 0
+                for i, (_, e, w) in enumerate(its):
+                    T, K, N, st, sk, sn, flip = e.args
+                    arr[i] = (w.data_ptr(), e.ptr, st, sk, sn, T, K, N, flip, K, N, int(e.k8), b0, e.ldn, 0)
+                    b0 += (T * K * N + blk - 1) // blk
+                tab = self._tables[tkey] = (self._upload(arr), b0, len(its))
+            dev_ptr, total, n = tab
+            L.check(L.fn("umi_pack_kn_multi")(dev_ptr, n, total, L.UMI_F32 if dtype == torch.float32 else L.UMI_F16,
+                                              _stream()), "umi_pack_kn_multi")
+            for _, e, w in its:
+                e.ver = self._ver(w)
+
+    def refresh(self):
+        """Bring every stale entry up to date: one umi_wstd_fwd_multi launch for the standardised weights, then one
+        umi_pack_kn_multi launch per storage dtype for the kernel layouts."""
+        # inside a HIP-graph capture everything is redone: the replayed graph must refresh the copies itself, whatever the
+        # parameter versions were when it was captured (e.g. a captured forward + backward whose optimizer step runs outside
+        # the graph: nothing is stale at capture time, everything is at the second replay)
         force = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
-        stale = {}
+        wst = []
+        for key, e in list(self.wstds.items()):
+            w = e.w()
+            if w is None:
+                del self.wstds[key]          # (its slot in the flat gradient buffers stays reserved)
+            elif force or e.ver != self._ver(w):
+                wst.append(e)
+        if wst:
+            dev_ptr, rows, n = self._wstd_table(wst)
+            L.check(L.fn("umi_wstd_fwd_multi")(dev_ptr, n, rows, _stream()), "umi_wstd_fwd_multi")
+            torch.autograd.graph.increment_version([e.ws for e in wst])
+            for e in wst:
+                e.ver = self._ver(e.w())
+        stale = []
         for key, e in list(self.ents.items()):
             w = e.w()
             if w is None:
                 del self.ents[key]
                 continue
-            # inside a HIP-graph capture every entry is re-packed: the replayed graph must refresh the copies itself, whatever
-            # the parameter versions were when it was captured (e.g. a captured forward + backward whose optimizer step runs
-            # outside the graph: nothing is stale at capture time, everything is at the second replay)
             if force or e.ver != self._ver(w):
-                stale.setdefault(e.dst.dtype, []).append((key, e, w))
-        blk = None
-        for dtype, items in stale.items():
-            tkey = tuple((k, w.data_ptr()) for k, _, w in items)
-            tab = self._tables.get(tkey)
-            if tab is None:
-                blk = blk or L.fn("umi_pack_block_elems")()
-                arr = np.zeros(len(items), dtype=_PACK_DESC)
-                b0 = 0
-                for i, (_, e, w) in enumerate(items):
-                    T, K, N, st, sk, sn, flip = e.args
-                    arr[i] = (w.data_ptr(), e.dst.data_ptr(), st, sk, sn, T, K, N, flip, K, N, int(e.k8), b0)
-                    b0 += (T * K * N + blk - 1) // blk
-                tab = self._tables[tkey] = (self._upload(arr), b0, len(items))
-            dev_ptr, total, n = tab
-            L.check(L.fn("umi_pack_kn_multi")(dev_ptr, n, total, L.UMI_F32 if dtype == torch.float32 else L.UMI_F16,
-                                              _stream()), "umi_pack_kn_multi")
-            for _, e, w in items:
-                e.ver = self._ver(w)
+                stale.append((key, e, w))
+        if stale:
+            self._repack(stale)
 
 
 def _np_dtypes():
     import numpy as np
     pack = np.dtype([("src", "u8"), ("dst", "u8"), ("st", "i8"), ("sk", "i8"), ("sn", "i8"), ("T", "i4"), ("K", "i4"),
-                     ("N", "i4"), ("flip", "i4"), ("Kpad", "i4"), ("Npad", "i4"), ("k8", "i4"), ("blk0", "i4")])
+                     ("N", "i4"), ("flip", "i4"), ("Kpad", "i4"), ("Npad", "i4"), ("k8", "i4"), ("blk0", "i4"),
+                     ("ldn", "i4"), ("pad", "i4")])
     opt = np.dtype([("p", "u8"), ("g", "u8"), ("s0", "u8"), ("s1", "u8"), ("n", "i8"), ("blk0", "i4"), ("pad", "i4")])
-    assert pack.itemsize == 72 and opt.itemsize == 48          # sizeof(umi_pack_desc) / sizeof(umi_optim_desc)
-    return pack, opt
+    wstd = np.dtype([("w", "u8"), ("ws", "u8"), ("rstd", "u8"), ("off", "i8"), ("Co", "i4"), ("K", "i4"), ("eps", "f4"),
+                     ("blk0", "i4")])
+    # sizeof(umi_pack_desc) / sizeof(umi_optim_desc) / sizeof(umi_wstd_desc)
+    assert pack.itemsize == 80 and opt.itemsize == 48 and wstd.itemsize == 48
+    return pack, opt, wstd
 
 
-_PACK_DESC, OPTIM_DESC = _np_dtypes()
+_PACK_DESC, OPTIM_DESC, _WSTD_DESC = _np_dtypes()
 
 
 # ------------------------------------------------------------------------------------------

@@ -151,7 +151,4 @@ def bilinear2x(x, y, backward=False, tx=None):
             "umi_bilinear2x")
 
 
-def pack_conv_dgrad_strided(w, dtype, k8=False):
-    """OIHW -> [R*S][Co][Ci] unflipped, for UMI_CONV_DGRAD_STRIDED (k8: the MFMA kernels' [R*S][Co/8][Ci][8])."""
-    Co, Ci, R, S = w.shape
-    return pack_kn(w, R * S, Co, Ci, 1, Ci * R * S, R * S, False, dtype, k8=k8)
+from .ops import pack_conv_dgrad_strided  # noqa: E402,F401  (kept under its old name)
