@@ -159,6 +159,12 @@ int umi_conv_wgrad(const void* x, int ldx, const void* txa, const void* dy, int 
                    float* dW, long s_co, long s_ci, long s_t, float out_scale,
                    int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
                    int Ho, int Wo, int dtype, int flags, void* ws, size_t ws_bytes, umi_stream_t stream);
+/* umi_conv_wgrad (R = S = 1, no transforms) for `n` layers of one shape in one launch: the per-layer weight gradients of a
+ * ViT encoder (reference vit_seg_modeling.py:58-62,100-101, twelve Blocks), whose pixel dimension (tokens) is too short to
+ * fill the chip one layer at a time without a deep split-K.  x / dy / dW: HOST arrays of n device pointers.  No workspace,
+ * deterministic.  UMI_ERR_UNSUPPORTED where the pointwise matrix-core kernel does not apply (call umi_conv_wgrad per layer). */
+int umi_conv_wgrad_group(int n, const void* const* x, int ldx, const void* const* dy, int lddy, float* const* dW, long s_co,
+                         long s_ci, float out_scale, long M, int Ci, int Co, int dtype, umi_stream_t stream);
 /* umi_conv_wgrad of a 3x3/stride-1/pad-1 conv fused with umi_bn_bwd_apply of the BatchNorm(+ReLU) that follows the conv
  * (reference Model.py:14-21 DoubleConv backward: autograd runs cudnn_batch_norm_backward, then convolution_backward):
  * `da` = gradient of the activated output (read only), `y`/`tx_bn`/`rstd`/`sum_dz`/`sum_dzx` as umi_bn_bwd_apply takes them;

@@ -487,3 +487,25 @@ def test_wgrad1x1_mfma_partial_channel_tiles(shape):
     assert torch.isfinite(res["mfma"]).all()
     assert (res["generic"] - ref).abs().max().item() < 2e-3 * scale
     assert (res["mfma"] - ref).abs().max().item() < 4e-3 * scale
+
+
+@pytest.mark.parametrize("n,M,Ci,Co,strided", [(12, 4704, 768, 768, False), (3, 301, 256, 384, False), (18, 150, 72, 136, False),
+                                                (4, 640, 128, 256, True)])
+def test_grouped_pointwise_wgrad_matches_per_layer_launches(n, M, Ci, Co, strided):
+    """umi_conv_wgrad_group (the weight gradients of n same-shaped linears in one launch, no split-K) against n
+    umi_conv_wgrad calls and an fp32 matmul: more than 16 problems (two launches), ragged row / channel tiles, and operands
+    that are column slices of wider tensors (the fused Q/K/V gradient)."""
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(n * M)
+    pad = 64 if strided else 0
+    xs = [torch.randn(1, 1, M, Ci + pad, generator=g).half().to(DEV)[..., pad // 2:pad // 2 + Ci] for _ in range(n)]
+    dys = [(torch.randn(1, 1, M, Co + pad, generator=g) * 0.1).half().to(DEV)[..., pad // 2:pad // 2 + Co] for _ in range(n)]
+    gws = [torch.full((Co, Ci), float("nan"), device=DEV) for _ in range(n)]
+    assert ops.conv_wgrad_group(xs, dys, gws, Ci, 1, 0.25)
+    for x, dy, gw in zip(xs, dys, gws):
+        ref = 0.25 * (dy[0, 0].float().t() @ x[0, 0].float())
+        one = torch.empty(Co, Ci, device=DEV)
+        ops.conv_wgrad(x, None, dy, None, one, Ci, 1, 1, 0.25, 1, 1, 1, 0)
+        scale = ref.abs().max().item()
+        assert (gw - ref).abs().max().item() < 2e-3 * scale          # fp16 operands, fp32 accumulation
+        assert (gw - one).abs().max().item() < 1e-4 * scale          # same products, another summation order

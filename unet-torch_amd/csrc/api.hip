@@ -84,6 +84,8 @@ int umi_wgrad_gather_mfma(const void* x, int ldx, const void* txa, const void* d
 bool umi_wgrad3x3_mfma_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
                           int ldx, int lddy, int dtype, int flags, const void* txb);
 size_t umi_wgrad3x3_mfma_ws_bytes(int N, int H, int W, int Ci, int Co);
+int umi_wgrad1x1_mfma_group(int n, const void* const* x, int ldx, const void* const* dy, int lddy, float* const* dW, long s_co,
+                            long s_ci, float out_scale, long M, int Ci, int Co, hipStream_t s);
 int umi_wgrad3x3_mfma_bnapply(const void* x, int ldx, const void* txa, const void* da, int ldda, const void* ybn, int ldybn,
                               const void* txbn, const float* rstd, const float* sum_dz, const float* sum_dzx, void* dz,
                               int lddz, float* dW, long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci,
@@ -297,6 +299,19 @@ extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co,
         if (m > g) g = m;
     }
     return g;
+}
+
+// umi_conv_wgrad for `n` pointwise convs / nn.Linear layers of ONE shape (M rows, Ci -> Co, same row strides) in one launch:
+// dW[i][co*s_co + ci*s_ci] = out_scale * sum_p x[i][p][ci] * dy[i][p][co].  No workspace: each output tile is owned by one
+// workgroup (fixed summation order).  UMI_ERR_UNSUPPORTED where the pointwise matrix-core kernel does not apply.
+extern "C" int umi_conv_wgrad_group(int n, const void* const* x, int ldx, const void* const* dy, int lddy, float* const* dW,
+                                    long s_co, long s_ci, float out_scale, long M, int Ci, int Co, int dtype,
+                                    umi_stream_t stream) {
+    if (n <= 0 || !x || !dy || !dW || M <= 0 || Ci <= 0 || Co <= 0 || ldx < Ci || lddy < Co) return UMI_ERR_BADARG;
+    for (int i = 0; i < n; ++i)
+        if (!x[i] || !dy[i] || !dW[i]) return UMI_ERR_BADARG;
+    if (!umi_wgrad1x1_mfma_ok(M, Ci, Co, 1, 1, 1, 0, ldx, lddy, dtype, 0, nullptr)) return UMI_ERR_UNSUPPORTED;
+    return umi_wgrad1x1_mfma_group(n, x, ldx, dy, lddy, dW, s_co, s_ci, out_scale, M, Ci, Co, (hipStream_t)stream);
 }
 
 // Weight gradient of a 3x3 conv whose output feeds BatchNorm(+ReLU), fused with stage 3 of that BatchNorm's backward: the

@@ -16,6 +16,7 @@
 // 3 taps x 4 rows.  Split-K over pixel tiles; partial slabs [split][tap][ci][co] fp32 are reduced in
 // fixed order (deterministic) by wgrad_reduce_kernel into the parameter's own layout.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -726,13 +727,21 @@ void plan(int N, int H, int W, int Ci, int Co, int* tiles_x, int* tiles_y, int* 
 // GATHER: weight gradient of any R x S conv with stride / padding (TransUNet's stride-2 convs, resnet_skip.py:52-60):
 // blockIdx.z = tap, dy rows stay linear, the x row of dy pixel (n, ho, wo) is (n, s*ho + ty - pad, s*wo + tx - pad),
 // zero outside the image:  dW[tap][ci][co] = sum_p tx(x[gather(p, tap)])[ci] * dy[p][co].
+// GROUP: up to 16 independent problems of ONE shape in a launch (blockIdx.z = problem; operands from the table in the kernel
+// arguments), no split-K: every workgroup runs the whole pixel range and stores its tile straight into the parameter-layout
+// gradient.  For the twelve encoder layers of a ViT, whose per-layer weight gradients (K = 4,704 tokens, 36..144 channel
+// tiles) each fill the chip only with a 7..9-way split -- slabs written and re-read that cost more than the GEMM.
 struct WGeo { int Ho, Wo, H, W, S, stride, pad; };
-template <int TM, bool HAS_TX, bool GATHER>
+struct WGroup { const half_t* x[16]; const half_t* dy[16]; float* dW[16]; long s_co, s_ci; float scale; };
+struct WNoGroup {};
+template <int TM, bool HAS_TX, bool GATHER, bool GROUP = false>
 __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __restrict__ x, int ldx,
                                                                const float4* __restrict__ tx,
                                                                const half_t* __restrict__ dy, int lddy,
                                                                float* __restrict__ part, long M, int Ci, int Co,
-                                                               int tiles_total, int tiles_per_split, int n_co_t, WGeo geo) {
+                                                               int tiles_total, int tiles_per_split, int n_co_t, WGeo geo,
+                                                               typename std::conditional<GROUP, WGroup, WNoGroup>::type grp) {
+    if constexpr (GROUP) { x = grp.x[blockIdx.z]; dy = grp.dy[blockIdx.z]; }
     constexpr int MT = TM / 64;                       // 32x32 tiles per wave per dimension
     constexpr int NCH = TM / 32;                      // 32-channel chunks per operand
     constexpr int CHB = 64 * PROW + 64;               // bytes per chunk (64 pixel rows; +64: see A_CHUNK)
@@ -850,7 +859,11 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_mfma_kernel(const half_t* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci0 + (wci * T16 + ta) * 16 + 4 * (lane >> 4) + r;
-                if (ci < Ci) part[(((long)blockIdx.y * gridDim.z + blockIdx.z) * Ci + ci) * Co + co] = acc[ta][tb][r];
+                if constexpr (GROUP) {
+                    if (ci < Ci) grp.dW[blockIdx.z][(long)co * grp.s_co + (long)ci * grp.s_ci] = acc[ta][tb][r] * grp.scale;
+                } else {
+                    if (ci < Ci) part[(((long)blockIdx.y * gridDim.z + blockIdx.z) * Ci + ci) * Co + co] = acc[ta][tb][r];
+                }
             }
         }
 }
@@ -905,13 +918,41 @@ int umi_wgrad1x1_mfma(const void* x, int ldx, const void* txa, const void* dy, i
     const int n_co_t = (Co + TM - 1) / TM;
     dim3 grid(((Ci + TM - 1) / TM) * n_co_t, splits), block(256);
     const WGeo geo{1, 1, 1, 1, 1, 1, 0};
-#define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_, false>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t, geo)
+#define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_, false>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t, geo, WNoGroup{})
     if (TM == 128) { if (txa) GO(128, true); else GO(128, false); }
     else { if (txa) GO(64, true); else GO(64, false); }
 #undef GO
     UMI_LAUNCH_CHECK();
     umi_launch_wgrad_reduce((const float*)ws, splits, 1, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
     UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// Weight gradients of `n` pointwise convs / linears of one shape in one launch per 16 (see GROUP above)
+int umi_wgrad1x1_mfma_group(int n, const void* const* x, int ldx, const void* const* dy, int lddy, float* const* dW, long s_co,
+                            long s_ci, float out_scale, long M, int Ci, int Co, hipStream_t s) {
+    const bool t128 = Ci % 128 == 0 && Co % 128 == 0 && (long)(Ci / 128) * (Co / 128) * (n < 16 ? n : 16) >= 96;
+    const int TM = t128 ? 128 : 64;
+    const int tt = (int)((M + 63) / 64), n_co_t = (Co + TM - 1) / TM;
+    const WGeo geo{1, 1, 1, 1, 1, 1, 0};
+    for (int g0 = 0; g0 < n; g0 += 16) {
+        const int cnt = n - g0 < 16 ? n - g0 : 16;
+        WGroup grp;
+        for (int i = 0; i < 16; ++i) {
+            const int j = g0 + (i < cnt ? i : 0);
+            if (((uintptr_t)x[j] | (uintptr_t)dy[j]) & 15) return UMI_ERR_BADARG;
+            grp.x[i] = (const half_t*)x[j]; grp.dy[i] = (const half_t*)dy[j]; grp.dW[i] = dW[j];
+        }
+        grp.s_co = s_co; grp.s_ci = s_ci; grp.scale = out_scale;
+        dim3 grid(((Ci + TM - 1) / TM) * n_co_t, 1, cnt), block(256);
+        if (TM == 128)
+            hipLaunchKernelGGL((wgrad1x1_mfma_kernel<128, false, false, true>), grid, block, 0, s, (const half_t*)nullptr, ldx,
+                               (const float4*)nullptr, (const half_t*)nullptr, lddy, (float*)nullptr, M, Ci, Co, tt, tt, n_co_t, geo, grp);
+        else
+            hipLaunchKernelGGL((wgrad1x1_mfma_kernel<64, false, false, true>), grid, block, 0, s, (const half_t*)nullptr, ldx,
+                               (const float4*)nullptr, (const half_t*)nullptr, lddy, (float*)nullptr, M, Ci, Co, tt, tt, n_co_t, geo, grp);
+        UMI_LAUNCH_CHECK();
+    }
     return UMI_OK;
 }
 
@@ -945,7 +986,7 @@ int umi_wgrad_gather_mfma(const void* x, int ldx, const void* txa, const void* d
     const int n_co_t = Co / TM;
     dim3 grid((Ci / TM) * n_co_t, splits, taps), block(256);
     const WGeo geo{Ho, Wo, H, W, S, stride, pad};
-#define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_, true>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t, geo)
+#define GO(T_, H_) hipLaunchKernelGGL((wgrad1x1_mfma_kernel<T_, H_, true>), grid, block, 0, s, (const half_t*)x, ldx, (const float4*)txa, (const half_t*)dy, lddy, (float*)ws, M, Ci, Co, tt, tps, n_co_t, geo, WNoGroup{})
     if (TM == 128) { if (txa) GO(128, true); else GO(128, false); }
     else { if (txa) GO(64, true); else GO(64, false); }
 #undef GO

@@ -14,6 +14,11 @@ from . import ops, ops_tu
 from .graph import Act, Tape, _wants_grad
 
 
+def _no_wgrad_group():
+    import os
+    return os.environ.get("UMI_NO_WGRAD_GROUP") == "1"           # A/B knob, read per call
+
+
 class TUTape(Tape):
     def __init__(self, *a, seed=0, seed_dev=None, **k):
         super().__init__(*a, **k)
@@ -21,14 +26,41 @@ class TUTape(Tape):
         self._seed_dev = seed_dev         # int32 device scalar mixed into every dropout seed inside the kernel: a step replayed
         self._drop_count = 0              # from a captured HIP graph (host-side `seed` frozen) still draws fresh masks
         self._wstd_pending, self._wstd_flat = [], None
+        self._wgrad_groups, self._deferred_dy = {}, set()
 
     # gradients of a value with several consumers are summed by a libunetmi kernel (no torch arithmetic)
     def _give(self, act, g):
         if act.parts is None and act.needs_grad and act.grad is not None:
             act.gives += 1
+            if act.grad.data_ptr() in self._deferred_dy:       # a deferred weight gradient still reads this buffer
+                tgt = torch.empty_like(act.grad)
+                ops_tu.add(act.grad, g, tgt)
+                act.grad = tgt
+                return
             ops_tu.add(act.grad, g, act.grad)
             return
         super()._give(act, g)
+
+    # ---- weight gradients of the token linears, deferred to the end of the backward pass and run per SHAPE: one launch for
+    # the twelve encoder layers' fc1 weights, one for fc2, ... (umi_conv_wgrad_group).  One layer at a time these GEMMs have
+    # only 4,704 rows to reduce over and 36-144 output tiles: filling 256 CUs took a 7-9-way split-K whose slabs cost more
+    # than the GEMM.  288 GB of HBM keep the ~0.8 GB of operands alive until then.
+    def _defer_wgrad(self, weight, x, tx, dy, gw, s_co, s_ci):
+        if (tx is not None or self.grad_sink is not None or self.dtype != torch.float16 or id(weight) in self.param_grads
+                or _no_wgrad_group()):
+            return False
+        key = (tuple(x.shape), x.stride(), tuple(dy.shape), dy.stride(), s_co, s_ci)
+        self._wgrad_groups.setdefault(key, []).append((x, dy, gw))
+        self._deferred_dy.add(dy.data_ptr())
+        return True
+
+    def _flush_wgrad_groups(self):
+        for (xs_, _, dys_, _, s_co, s_ci), items in self._wgrad_groups.items():
+            xs, dys, gws = zip(*items)
+            if len(items) < 2 or not ops.conv_wgrad_group(xs, dys, gws, s_co, s_ci, self.inv):
+                for x, dy, gw in items:
+                    ops.conv_wgrad(x, None, dy, None, gw, s_co, s_ci, 1, self.inv, 1, 1, 1, 0)
+        self._wgrad_groups, self._deferred_dy = {}, set()
 
     # ---- convolution with weight standardisation (no bias), output stored raw == activated -----------------------
     def std_conv(self, a: Act, conv):
@@ -90,9 +122,11 @@ class TUTape(Tape):
 
     def backward(self):
         self._wstd_pending, self._wstd_flat = [], None
+        self._wgrad_groups, self._deferred_dy = {}, set()
         super().backward()
 
     def _finish_param_grads(self):
+        self._flush_wgrad_groups()
         if self._wstd_pending:
             self.pack_cache.wstd_bwd(self._wstd_pending, *self._wstd_flat)
             self._wstd_pending = []
@@ -183,7 +217,8 @@ class TUTape(Tape):
                 if o.grad is None:
                     return
                 gw = self._new_pgrad(weight)
-                ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci, 1, 1, self.inv, 1, 1, 1, 0)
+                if not self._defer_wgrad(weight, a.raw, a.tx, o.grad, gw, Ci, 1):
+                    ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci, 1, 1, self.inv, 1, 1, 1, 0)
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
@@ -335,7 +370,9 @@ class TUTape(Tape):
                 dqkv = self.alloc(N, H, W, 3 * C, device=out.device)
                 ops_tu.attn_bwd(q, k, v, out, o.grad, lse, *(dqkv[..., i * C:(i + 1) * C] for i in range(3)), heads)
                 gw = torch.empty(3 * C, C, dtype=torch.float32, device=out.device)
-                ops.conv_wgrad(a.raw, a.tx, dqkv, None, gw, C, 1, 1, self.inv, 1, 1, 1, 0)
+                if any(id(m.weight) in self.param_grads for m in mods) or not self._defer_wgrad(query.weight, a.raw, a.tx, dqkv,
+                                                                                                 gw, C, 1):
+                    ops.conv_wgrad(a.raw, a.tx, dqkv, None, gw, C, 1, 1, self.inv, 1, 1, 1, 0)
                 gb = torch.empty(3 * C, dtype=torch.float32, device=out.device)
                 ops.colsum(dqkv, gb, self.inv)
                 for i, m in enumerate(mods):

@@ -624,6 +624,27 @@ def conv_wgrad(x, txa, dy, txb, dW, s_co, s_ci, s_t, out_scale, R, S, stride, pa
                                    _dt(x), flags, ws.data_ptr(), ws.numel(), _stream()), "umi_conv_wgrad")
 
 
+def conv_wgrad_group(xs, dys, dWs, s_co, s_ci, out_scale):
+    """umi_conv_wgrad_group: the weight gradients of len(xs) pointwise layers of one shape in one launch; False where the
+    matrix-core kernel does not apply (nothing was launched)."""
+    import ctypes
+    n = len(xs)
+    N, H, W, Ci, ldx = _nhwc(xs[0])
+    _, _, _, Co, lddy = _nhwc(dys[0])
+    for x, dy, dW in zip(xs, dys, dWs):
+        assert _nhwc(x) == (N, H, W, Ci, ldx) and _nhwc(dy) == (N, H, W, Co, lddy) and x.dtype == xs[0].dtype
+        assert dW.dtype == torch.float32
+    arr = ctypes.c_void_p * n
+    ptrs = [arr(*[t.data_ptr() for t in ts]) for ts in (xs, dys, dWs)]
+    st = L.fn("umi_conv_wgrad_group")(n, ctypes.cast(ptrs[0], ctypes.c_void_p), ldx, ctypes.cast(ptrs[1], ctypes.c_void_p), lddy,
+                                      ctypes.cast(ptrs[2], ctypes.c_void_p), s_co, s_ci, out_scale, N * H * W, Ci, Co,
+                                      _dt(xs[0]), _stream())
+    if st == -2:
+        return False
+    L.check(st, "umi_conv_wgrad_group")
+    return True
+
+
 def colsum(x, out, out_scale):
     N, H, W, C, ldx = _nhwc(x)
     M = N * H * W
