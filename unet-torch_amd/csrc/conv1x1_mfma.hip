@@ -16,13 +16,18 @@
 // into LDS rows of 144 B (128 B data + 16 B pad = 9 slots, odd -> conflict-free ds_read_b128), consumer-side
 // BN+ReLU transform applied on the way.  Epilogue through an LDS tile for 16-B coalesced (scattered) stores.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+constexpr int OUT_UPS_TAPS_MAX = 49;     // most taps a packed weight tensor of this kernel has (R*S <= 49)
 
 // pixels per workgroup tile: template parameter P (256, or 128 when the grid would not fill the chip)
 constexpr int CK = 64;        // K chunk
@@ -61,25 +66,41 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
     const int sub = tid & 7;
 
     // ---- staging plan --------------------------------------------------------------------------------
+    // dense: a plain pointwise conv whose source and destination are whole tensors (token linears, bottleneck 1x1 convs): pixel m
+    // is row m of both, none of the index arithmetic below (64-bit divisions: ~2 us of a 17-us launch) is needed
+    const bool dense = !GATHER && !OUT_UPS && geo.Hs == geo.h && geo.Ws == geo.w && geo.Hd == geo.h && geo.Wd == geo.w;
+    const long n0img = dense ? 0 : m0 / ((long)geo.h * geo.w);     // first image of this tile: source offsets are relative to it
+    // K chunks in flight per thread (global -> registers), D - 1 of them while the matrix cores work on another: with the
+    // 128-pixel tiles (ViT linears: 4,704 tokens, ~1.7 workgroups per CU) one chunk's MFMA phase is ~500 cycles against
+    // ~2,000 of load latency, and with a single chunk in flight the loop ran at the latency (17 us for K = 768, 55 us for
+    // K = 3,072: 12 / 48 chunks x ~1.2 us)
+#ifdef UMI_C1_DEPTH            /* timing experiments: one depth for every tile */
+    constexpr int D = UMI_C1_DEPTH;
+#else
+    // measured (same box, whole steps): a second set helps the 256 x 64 tiles (U-Net transposed convs 24.6 -> 24.3 ms/step),
+    // the 128-pixel tiles are best with one (TransUNet 20.85 ms/step against 21.1 with three, 21.6 with two everywhere) -- they
+    // are bound by LDS traffic per MFMA, not by the load latency; 256 x 128 has no registers for a second set
+    constexpr int D = (P == 256 && BN == 64) ? 2 : 1;
+#endif
     long xoff[KPX];                           // plain: element offset of this thread's pixel k in the source, or -1
     int nH[KPX], by[KPX], bx[KPX];            // GATHER: image row base n*Hs and the tap-0 source coordinate of pixel k
-    bool xv[KPX];                             // this pixel's piece of the chunk in flight is inside the image
+    bool xv[D][KPX];                          // this pixel's piece of the chunk held in register set d exists (image and K range)
 #pragma unroll
     for (int k = 0; k < KPX; ++k) {
         long m = m0 + (tid >> 3) + 32 * k;
         xoff[k] = -1;
         nH[k] = 0; by[k] = -(1 << 28); bx[k] = 0;          // far outside: every tap of a pixel beyond M is "padding"
-        xv[k] = m < M;
-        if (m < M) {
+        if (m < M && dense) xoff[k] = (m - m0) * ldx + sub * 8;
+        else if (m < M) {
             int n = (int)(m / ((long)geo.h * geo.w));
             int r = (int)(m - (long)n * geo.h * geo.w);
             int yy = r / geo.w, xx = r - yy * geo.w;
             if (sub == 0) pixinfo[(tid >> 3) + 32 * k] = make_int2(n, (yy << 16) | xx);
             if (GATHER) {
-                nH[k] = n * geo.Hs;
+                nH[k] = (n - (int)n0img) * geo.Hs;
                 by[k] = geo.frac ? yy + geo.pad : yy * geo.stride - geo.pad + geo.soy;
                 bx[k] = geo.frac ? xx + geo.pad : xx * geo.stride - geo.pad + geo.sox;
-            } else xoff[k] = ((long)((long)n * geo.Hs + yy) * geo.Ws + xx) * ldx + sub * 8;
+            } else xoff[k] = ((long)((long)(n - n0img) * geo.Hs + yy) * geo.Ws + xx) * ldx + sub * 8;
         }
     }
     long woff[KPW];                           // element offset of weight row k (chunk 0)
@@ -108,21 +129,33 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
-    half8 xraw[KPX], wraw[KPW];
-    half8 zero8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
+    // (kept as 4 x 32 bit: a half8 carried around the loop is split into sixteen-bit values by the compiler, with the unpacking --
+    // and a wait for the load -- right behind the load)
+    u32x4 xraw[D][KPX], wraw[D][KPW];
+    // Every load is unconditional: a piece outside the image / the K range / the channel range gets an offset past the end
+    // of its buffer resource and comes back as zeros.  (`cond ? *p : zero` compiled to a branch per load and a
+    // s_waitcnt vmcnt(0) right behind the loads: the whole global-memory latency sat in front of every chunk's MFMA phase --
+    // 17 us for the 12 chunks of a 4,704 x 768 x 768 linear.)
+    constexpr unsigned OOB = 0x7FFFFFFFu;
+    // (the source resource starts at the first image this tile touches -- n0img, below -- so that 31-bit offsets are enough
+    // for any tensor whose single images are below 1 GB)
+    const long ximg_bytes = (long)geo.Hs * geo.Ws * ldx * 2;
+    const long xleft = dense ? (M - m0) * ldx * 2 : (M / ((long)geo.h * geo.w) - n0img) * ximg_bytes;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)x + (dense ? m0 * ldx * 2 : n0img * ximg_bytes)), 0, (int)(xleft > 0x7FFFFFF0L ? 0x7FFFFFF0L : xleft), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)wp8, 0, (int)((long)(OUT_UPS ? 4 : ntaps) * Kc * Nc * 2), 0x00020000);
 
     const int chunks_per_tap = (Kc + CK - 1) / CK;        // plain mode accepts Kc % 8 == 0: the last chunk is partial
     const int nchunks = GATHER ? ntaps * chunks_per_tap : chunks_per_tap;
-#define UMI_ISSUE(c_)                                                                                              \
+#define UMI_ISSUE(c_, S_)                                                                                          \
     do {                                                                                                          \
         const int cc = (c_);                                                                                      \
         const int tap_in = GATHER ? cc / chunks_per_tap : 0;                                                      \
         const int kc = cc - tap_in * chunks_per_tap;                                                              \
         const long xadd = (long)kc * CK;                                                                          \
         const long wadd = ((long)tap_in * (Kc >> 3) + kc * 8) * Nc * 8;                                           \
-        const bool kin = kc * CK + sub * 8 < Kc;      /* this thread's 8 input channels exist in the chunk */     \
+        const bool kin = cc < nchunks && kc * CK + sub * 8 < Kc;   /* this thread's 8 input channels exist in the chunk */ \
         if (GATHER) {                                                                                             \
             const int ty = tap_in / geo.S, tx_ = tap_in - ty * geo.S;                                             \
             _Pragma("unroll") for (int k = 0; k < KPX; ++k) {                                                     \
@@ -134,16 +167,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
                     ys /= geo.stride; xs /= geo.stride;                                                           \
                 }                                                                                                 \
                 ok = ok && ys >= 0 && ys < geo.Hs && xs >= 0 && xs < geo.Ws;                                       \
-                xv[k] = ok;                                                                                       \
-                xraw[k] = ok ? *reinterpret_cast<const half8*>(x + ((long)(nH[k] + ys) * geo.Ws + xs) * ldx + sub * 8 + xadd) \
-                             : zero8;                                                                             \
+                xv[S_][k] = ok && kin;                                                                            \
+                xraw[S_][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(                    \
+                    xrs, xv[S_][k] ? (unsigned)((((long)(nH[k] + ys) * geo.Ws + xs) * ldx + sub * 8 + xadd) * 2) : OOB, 0, 0)); \
             }                                                                                                     \
         } else {                                                                                                  \
-            _Pragma("unroll") for (int k = 0; k < KPX; ++k)                                                       \
-                xraw[k] = (xoff[k] >= 0 && kin) ? *reinterpret_cast<const half8*>(x + xoff[k] + xadd) : zero8;    \
+            _Pragma("unroll") for (int k = 0; k < KPX; ++k) {                                                     \
+                xv[S_][k] = xoff[k] >= 0 && kin;                                                                  \
+                xraw[S_][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(                    \
+                    xrs, xv[S_][k] ? (unsigned)((xoff[k] + xadd) * 2) : OOB, 0, 0));                              \
+            }                                                                                                     \
         }                                                                                                         \
         _Pragma("unroll") for (int k = 0; k < KPW; ++k)                                                           \
-            wraw[k] = (wv[k] && kin) ? *reinterpret_cast<const half8*>(wp8 + woff[k] + wadd) : zero8;             \
+            wraw[S_][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(                        \
+                wrs, (wv[k] && kin) ? (unsigned)((woff[k] + wadd) * 2) : OOB, 0, 0));                             \
     } while (0)
 
     const int lrow = lane & 15, lgrp = lane >> 4;
@@ -164,50 +201,60 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
         }
         __syncthreads();
     }
-    UMI_ISSUE(0);
-    for (int c = 0; c < nchunks; ++c) {
-        if (HAS_TX) {
-            float4 t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = txbuf[c & 1][j * 8 + sub];
-#pragma unroll
-            for (int k = 0; k < KPX; ++k)
-                if (xv[k] && c * CK % (chunks_per_tap * CK) + sub * 8 < Kc) {
-                    xraw[k] = umi_tx8(xraw[k], t);
-                }
-        }
-#pragma unroll
-        for (int k = 0; k < KPX; ++k) *reinterpret_cast<half8*>(smem + xl + k * 32 * ROWB) = xraw[k];
-#pragma unroll
-        for (int k = 0; k < KPW; ++k) *reinterpret_cast<half8*>(smem + wl + k * 32 * ROWB) = wraw[k];
-        __syncthreads();
-        if (HAS_TX && tid < CK && c + 2 < nchunks) {
-            txbuf[c & 1][(tid & 7) * 8 + (tid >> 3)] = txr;                  // all readers of this buffer are past the barrier above
-            if (c + 3 < nchunks) txr = UMI_TXROW(c + 3);
-        }
-        if (c + 1 < nchunks) UMI_ISSUE(c + 1);
-        __builtin_amdgcn_s_setprio(3);              // MFMA phase outranks the other workgroup's staging (see conv_mfma.hip)
-#pragma unroll
-        for (int ks = 0; ks < CK / 32; ++ks) {
-            half8 af[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) af[ct] = *reinterpret_cast<const half8*>(smem + a_base + ct * 16 * ROWB + ks * 64);
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {            // pixel tiles in two halves: 4 + NT fragments live, not 4 + 2*NT
-                half8 bf[NT];
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-                    bf[i] = *reinterpret_cast<const half8*>(smem + b_base + (ph * NT + i) * 16 * ROWB + ks * 64);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-                        acc[ct][ph * NT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ct], bf[i], acc[ct][ph * NT + i], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+    // one K chunk: (transform,) registers of set S_ -> LDS, refill the set with chunk c + D, MFMA.  Every body issues its loads
+    // whether or not chunk c + D exists (past the end they are out-of-range = no memory access, zeros): with the same number of
+    // loads in flight on every path the compiler can wait for exactly this set's loads (vmcnt(2 x per-set loads)); with the
+    // issue under a condition it fell back to vmcnt(0) at the loop head and drained the whole pipeline once per D chunks.
+#define UMI_CHUNK(c_, S_)                                                                                          \
+    do {                                                                                                          \
+        const int c = (c_);                                                                                       \
+        const bool live = c < nchunks;                                                                            \
+        if (live) {                                                                                               \
+            if (HAS_TX) {                                                                                         \
+                float4 t[8];                                                                                      \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) t[j] = txbuf[c & 1][j * 8 + sub];                   \
+                _Pragma("unroll") for (int k = 0; k < KPX; ++k)                                                   \
+                    if (xv[S_][k]) xraw[S_][k] = __builtin_bit_cast(u32x4, umi_tx8(__builtin_bit_cast(half8, xraw[S_][k]), t)); \
+            }                                                                                                     \
+            _Pragma("unroll") for (int k = 0; k < KPX; ++k) *reinterpret_cast<u32x4*>(smem + xl + k * 32 * ROWB) = xraw[S_][k]; \
+            _Pragma("unroll") for (int k = 0; k < KPW; ++k) *reinterpret_cast<u32x4*>(smem + wl + k * 32 * ROWB) = wraw[S_][k]; \
+        }                                                                                                         \
+        __syncthreads();                                                                                          \
+        if (HAS_TX && tid < CK && c + 2 < nchunks) {                                                              \
+            txbuf[c & 1][(tid & 7) * 8 + (tid >> 3)] = txr;     /* all readers of this buffer are past the barrier above */ \
+            if (c + 3 < nchunks) txr = UMI_TXROW(c + 3);                                                          \
+        }                                                                                                         \
+        UMI_ISSUE(c + D, S_);                                                                                     \
+        if (live) {                                                                                               \
+            __builtin_amdgcn_s_setprio(3);          /* MFMA phase outranks the other workgroup's staging (see conv_mfma.hip) */ \
+            _Pragma("unroll") for (int ks = 0; ks < CK / 32; ++ks) {                                              \
+                half8 af[4];                                                                                      \
+                _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                                                  \
+                    af[ct] = *reinterpret_cast<const half8*>(smem + a_base + ct * 16 * ROWB + ks * 64);           \
+                _Pragma("unroll") for (int ph = 0; ph < 2; ++ph) {   /* pixel tiles in two halves: 4 + NT fragments live */ \
+                    half8 bf[NT];                                                                                 \
+                    _Pragma("unroll") for (int i = 0; i < NT; ++i)                                                \
+                        bf[i] = *reinterpret_cast<const half8*>(smem + b_base + (ph * NT + i) * 16 * ROWB + ks * 64); \
+                    _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                                              \
+                        _Pragma("unroll") for (int i = 0; i < NT; ++i)                                            \
+                            acc[ct][ph * NT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ct], bf[i], acc[ct][ph * NT + i], 0, 0, 0); \
+                }                                                                                                 \
+            }                                                                                                     \
+            __builtin_amdgcn_s_setprio(0);                                                                        \
+        }                                                                                                         \
+        __syncthreads();                                                                                          \
+    } while (0)
+
+    constexpr int S1 = D > 1 ? 1 : 0, S2 = D > 2 ? 2 : 0;          // (in-range indices for the sets a smaller D does not have)
+    UMI_ISSUE(0, 0);
+    if (D > 1) UMI_ISSUE(1, S1);
+    if (D > 2) UMI_ISSUE(2, S2);
+    for (int c0_ = 0; c0_ < nchunks; c0_ += D) {
+        UMI_CHUNK(c0_, 0);
+        if (D > 1) UMI_CHUNK(c0_ + 1, S1);
+        if (D > 2) UMI_CHUNK(c0_ + 2, S2);
     }
+#undef UMI_CHUNK
 #undef UMI_ISSUE
 #undef UMI_TXROW
 
@@ -249,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 #pragma unroll 4
         for (int p = p0; p < P; p += PSTEP) {
             if (m0 + p >= M || !col_ok) break;
-            const int2 pi = pixinfo[p];
+            const int2 pi = dense ? make_int2(0, 0) : pixinfo[p];
             int yy = pi.y >> 16, xx = pi.y & 0xffff;
             if (OUT_UPS) {
                 yy = 2 * yy + tdy;
@@ -257,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
                 if (yy < 0 || yy >= geo.Hd || xx < 0 || xx >= geo.Wd) continue;
             }
             uint4 v = *reinterpret_cast<const uint4*>(smem + p * ERS + j * 16);
-            half_t* dst = y + ((long)((long)pi.x * geo.Hd + yy) * geo.Wd + xx) * ldy + co;
+            half_t* dst = dense ? y + (m0 + p) * ldy + co : y + ((long)((long)pi.x * geo.Hd + yy) * geo.Wd + xx) * ldy + co;
             if (geo.accum) {
                 // a second gradient contribution lands on the tensor the first one wrote: same rounding as adding two
                 // stored fp16 tensors
@@ -306,6 +353,7 @@ bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int 
     const int mode = umi_conv1x1_mode(R, S, stride, pad, flags);
     if (mode < 0) return false;
     if (ldx % 8 || ldy % 8) return false;
+    if ((long)(OUT_UPS_TAPS_MAX) * Ci * Co * 2 >= 0x7FFFFFF0L) return false;        // weights behind one 31-bit buffer resource
     // plain 1x1: any Ci, Co that are multiples of 8 (partial last K chunk / output tile; the attention gates' 32-channel
     // branches); the tap-gather / transposed-conv modes keep whole 64-channel tiles
     if (mode == 0) return Ci % 8 == 0 && Co % 8 == 0 && Ci >= 16 && Co >= 16;
@@ -340,6 +388,14 @@ int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, co
     const long b_256_64 = ((M + 255) / 256) * (Ntot / 64);
     geo.accum = (flags & UMI_CONV_ACCUMULATE) ? 1 : 0;
 #define GO(P_, BN_) return launch<P_, BN_>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s)
+    // UMI_C1_TILE=PxBN: tile override for timing experiments (tools/ab_gemm.py); read per call
+    if (const char* e = getenv("UMI_C1_TILE")) {
+        const int p_ = atoi(e), bn_ = strchr(e, 'x') ? atoi(strchr(e, 'x') + 1) : 0;
+        if (p_ == 256 && bn_ == 128 && bn128) GO(256, 128);
+        if (p_ == 256 && bn_ == 64) GO(256, 64);
+        if (p_ == 128 && bn_ == 128 && bn128) GO(128, 128);
+        if (p_ == 128 && bn_ == 64) GO(128, 64);
+    }
     if (bn128 && b_256_128 >= want) GO(256, 128);
     if (b_256_64 >= want) GO(256, 64);
     if (bn128 && b_128_128 >= want) GO(128, 128);

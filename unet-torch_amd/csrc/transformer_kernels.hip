@@ -603,7 +603,7 @@ bool umi_gn_stats_f16v(const void* x, int ldx, int N, long HW, int C, int G, flo
                        hipStream_t s);
 bool umi_gn_bwd_reduce_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                             const float* rstd, const float* gamma, int relu, int N, long HW, int C, int G, float* gsum,
-                            float* part, float* ws, hipStream_t s);
+                            float* part, float* ws, int* tickets, float* dgamma, float* dbeta, float out_scale, hipStream_t s);
 // elementwise_tu_f16.hip
 bool umi_ew_f16v(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C, long bcast_rows,
                  hipStream_t s);
@@ -694,7 +694,7 @@ extern "C" size_t umi_gn_bwd_ws_bytes(int N, long HW, int C, int G) {
 extern "C" int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                           const float* rstd, const float* gamma, int relu, void* dx, int lddx, void* dres, int lddr,
                           float* dgamma, float* dbeta, float out_scale, int N, long HW, int C, int G, int dtype, void* ws,
-                          size_t ws_bytes, umi_stream_t st) {
+                          size_t ws_bytes, int* tickets, umi_stream_t st) {
     if (!dy || !y || !x || !dx || !dgamma || !dbeta || !ws || C % G) return UMI_ERR_BADARG;
     if (ws_bytes < umi_gn_bwd_ws_bytes(N, HW, C, G)) return UMI_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)st;
@@ -702,13 +702,16 @@ extern "C" int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, cons
     float* part = gsum + (size_t)N * G * 2;
     float* stage1 = part + (size_t)N * 2 * C;
     const int grid = grid_for((long)N * HW * C);
+    if (N >= 1024) tickets = nullptr;
     if (dtype == UMI_F16 && umi_gn_bwd_reduce_f16v(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, relu, N, HW, C, G, gsum, part,
-                                                    stage1, s)) {
+                                                    stage1, tickets, dgamma, dbeta, out_scale, s)) {
         if (!umi_gn_bwd_apply_f16v(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, gsum, relu, dx, lddx, dres, lddr, N, HW, C, G, s))
         hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx, (half_t*)dres, lddr, N, HW, C, G);
         UMI_LAUNCH_CHECK();
-        umi_launch_reduce_rows2(part, N, C, dgamma, dbeta, out_scale, s);
-        UMI_LAUNCH_CHECK();
+        if (!tickets) {                  // (with tickets the reduction kernel's last workgroup has written dgamma / dbeta)
+            umi_launch_reduce_rows2(part, N, C, dgamma, dbeta, out_scale, s);
+            UMI_LAUNCH_CHECK();
+        }
         return UMI_OK;
     }
     DT_SWITCH(dtype,

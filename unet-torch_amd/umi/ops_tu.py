@@ -11,6 +11,22 @@ def _rows(t):
     return N * H * W, C, ld
 
 
+_tickets = {}
+
+
+def tickets(device):
+    """Zeroed counters for the kernels that fold their last reduction stage into the last-arriving workgroups (they leave
+    them zero): one buffer per device + stream.  UMI_NO_TICKETS=1: None (separate second-stage launches; A/B knob)."""
+    import os
+    if os.environ.get("UMI_NO_TICKETS") == "1":
+        return None
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    t = _tickets.get(key)
+    if t is None:
+        t = _tickets[key] = torch.zeros(4096, dtype=torch.int32, device=device)
+    return t
+
+
 def wstd_fwd(w, eps=1e-5):
     Co = w.shape[0]
     K = w[0].numel()
@@ -50,7 +66,7 @@ def gn_bwd(dy, y, x, mean, rstd, gamma, groups, relu, dx, dres, out_scale):
     L.check(L.fn("umi_gn_bwd")(dy.data_ptr(), _nhwc(dy)[4], y.data_ptr(), _nhwc(y)[4], x.data_ptr(), ldx, mean.data_ptr(),
                                rstd.data_ptr(), gamma.data_ptr(), int(relu), dx.data_ptr(), _nhwc(dx)[4], _ptr(dres),
                                _nhwc(dres)[4] if dres is not None else 0, dg.data_ptr(), db.data_ptr(), out_scale, N, H * W,
-                               C, groups, _dt(x), ws.data_ptr(), ws.numel(), _stream()), "umi_gn_bwd")
+                               C, groups, _dt(x), ws.data_ptr(), ws.numel(), _ptr(tickets(x.device)), _stream()), "umi_gn_bwd")
     return dg, db
 
 
