@@ -180,6 +180,11 @@ int umi_conv_wgrad_bnapply(const void* x, int ldx, const void* txa, const void* 
 size_t umi_colsum_ws_bytes(long M, int C);
 int umi_colsum(const void* x, int ldx, float* out, float out_scale, long M, int C, int dtype,
                void* ws, size_t ws_bytes, umi_stream_t stream);
+/* umi_colsum for n fp16 tensors of one shape (C % 8 == 0) in two launches per 16: the bias gradients of a ViT's twelve
+ * encoder layers.  xs / outs: HOST arrays of device pointers; ws >= min(n,16) * umi_colsum_ws_bytes(M, C).
+ * UMI_ERR_UNSUPPORTED where the vectorised kernel does not apply (call umi_colsum per tensor). */
+int umi_colsum_group(int n, const void* const* xs, int ldx, float* const* outs, float out_scale, long M, int C, int dtype,
+                     void* ws, size_t ws_bytes, umi_stream_t stream);
 
 /* Materialise an activation (storage + consumer transform) as NCHW fp32: the tensor a
  * reference block returns (e.g. DoubleConv.forward, reference Model.py:25-26). */

@@ -509,3 +509,20 @@ def test_grouped_pointwise_wgrad_matches_per_layer_launches(n, M, Ci, Co, stride
         scale = ref.abs().max().item()
         assert (gw - ref).abs().max().item() < 2e-3 * scale          # fp16 operands, fp32 accumulation
         assert (gw - one).abs().max().item() < 1e-4 * scale          # same products, another summation order
+
+
+@pytest.mark.parametrize("n,M,C,strided", [(12, 4704, 3072, False), (18, 333, 72, False), (3, 1000, 768, True)])
+def test_grouped_colsum_matches_per_tensor_launches(n, M, C, strided):
+    """umi_colsum_group (bias gradients of n same-shaped layers, two launches per 16) against umi_colsum per tensor: the same
+    partial-row kernel body and the same fp64 second stage, so the results are identical."""
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(n + M + C)
+    pad = 64 if strided else 0
+    xs = [torch.randn(1, 1, M, C + pad, generator=g).half().to(DEV)[..., pad // 2:pad // 2 + C] for _ in range(n)]
+    outs = [torch.full((C,), float("nan"), device=DEV) for _ in range(n)]
+    assert ops.colsum_group(xs, outs, 0.5)
+    for x, o in zip(xs, outs):
+        one = torch.empty(C, device=DEV)
+        ops.colsum(x, one, 0.5)
+        assert torch.equal(o, one)
+        _close(o, x[0, 0].float().sum(0) * 0.5, 2e-3)

@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce1_v8(const half_t* __restric
 // SQ: also the per-channel sums of squares (slot 1 of the partial rows): BatchNorm statistics of a tensor whose producer has
 // no statistics epilogue (the pointwise MFMA convolution of the attention gates)
 template <bool SQ = false>
-__global__ __launch_bounds__(256) void colsum_v8(const half_t* __restrict__ x, int ldx, float* __restrict__ ws, long M, int C,
-                                                 int RPB) {
+__device__ __forceinline__ void colsum_v8_body(const half_t* __restrict__ x, int ldx, float* __restrict__ ws, long M, int C,
+                                               int RPB) {
     __shared__ float red[256][9];
     float q0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x;
@@ -135,6 +135,35 @@ __global__ __launch_bounds__(256) void colsum_v8(const half_t* __restrict__ x, i
             ws[((long)blockIdx.x * 2 + 1) * C + gb * 8 + cl] = a;
         }
     }
+}
+
+template <bool SQ = false>
+__global__ __launch_bounds__(256) void colsum_v8(const half_t* __restrict__ x, int ldx, float* __restrict__ ws, long M, int C,
+                                                 int RPB) {
+    colsum_v8_body<SQ>(x, ldx, ws, M, C, RPB);
+}
+// up to 16 tensors of one shape per launch (blockIdx.z): the bias gradients of the twelve encoder layers of a ViT
+struct CsGroup { const half_t* x[16]; float* out[16]; };
+__global__ __launch_bounds__(256) void colsum_group_v8(CsGroup grp, int ldx, float* __restrict__ ws, long ws_stride, long M, int C,
+                                                       int RPB) {
+    colsum_v8_body<false>(grp.x[blockIdx.z], ldx, ws + blockIdx.z * ws_stride, M, C, RPB);
+}
+// second stage of the grouped launch: out[g][c] = scale * sum over the partial rows (slot 0) of group g, fp64, fixed order
+// (reduce_rows2_kernel's arithmetic)
+__global__ __launch_bounds__(256) void colsum_group_reduce(CsGroup grp, const float* __restrict__ ws, long ws_stride, int rows, int C,
+                                                           float scale) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float* w = ws + blockIdx.y * ws_stride;
+    double a = 0.0;
+    for (int r = tid; r < rows; r += 256) a += (double)w[((long)r * 2 + 0) * C + c];
+    sh[tid] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) grp.out[blockIdx.y][c] = (float)(sh[0] * (double)scale);
 }
 
 // ---- BN + ReLU backward, stage 3: dy = gamma*rstd * (dz - sum_dz/M - xhat*sum_dzx/M), in place ---------------
@@ -321,6 +350,24 @@ bool umi_colsum_f16v(const void* x, int ldx, float* ws, long M, int C, hipStream
     const int rpb = rpb_colsum(M, C);
     hipLaunchKernelGGL(colsum_v8<false>, dim3((unsigned)((M + rpb - 1) / rpb), (C / 8 + 255) / 256), dim3(256), 0, s, (const half_t*)x, ldx, ws,
                        M, C, rpb);
+    return true;
+}
+// n tensors of one shape: partial rows of tensor g at ws + g * rows * 2 * C, then outs[g] <- scale * column sums
+bool umi_colsum_group_f16v(int n, const void* const* xs, int ldx, float* const* outs, float scale, float* ws, long M, int C,
+                           hipStream_t s) {
+    const int rows = umi_colsum_rows_f16v(M, C);
+    if (!rows || ldx % 8) return false;
+    for (int i = 0; i < n; ++i)
+        if (!al16(xs[i])) return false;
+    const int rpb = rpb_colsum(M, C);
+    const long stride = (long)rows * 2 * C;
+    for (int g0 = 0; g0 < n; g0 += 16) {
+        const int cnt = n - g0 < 16 ? n - g0 : 16;
+        CsGroup grp;
+        for (int i = 0; i < 16; ++i) { const int j = g0 + (i < cnt ? i : 0); grp.x[i] = (const half_t*)xs[j]; grp.out[i] = outs[j]; }
+        hipLaunchKernelGGL(colsum_group_v8, dim3((unsigned)rows, (C / 8 + 255) / 256, cnt), dim3(256), 0, s, grp, ldx, ws, stride, M, C, rpb);
+        hipLaunchKernelGGL(colsum_group_reduce, dim3(C, cnt), dim3(256), 0, s, grp, (const float*)ws, stride, rows, C, scale);
+    }
     return true;
 }
 // BatchNorm statistics pass: part[rows][2][C] = per-block sums and sums of squares of x (rows = umi_colsum_rows_f16v)

@@ -609,6 +609,22 @@ extern "C" size_t umi_colsum_ws_bytes(long M, int C) {
     return b;
 }
 
+// umi_colsum for n tensors of one shape in two launches per 16 (fp16, C % 8 == 0; UMI_ERR_UNSUPPORTED otherwise): `ws` needs
+// min(n, 16) * umi_colsum_ws_bytes(M, C) bytes
+bool umi_colsum_group_f16v(int n, const void* const* xs, int ldx, float* const* outs, float scale, float* ws, long M, int C,
+                           hipStream_t s);
+extern "C" int umi_colsum_group(int n, const void* const* xs, int ldx, float* const* outs, float out_scale, long M, int C,
+                                int dtype, void* ws, size_t ws_bytes, umi_stream_t stream) {
+    if (n <= 0 || !xs || !outs || M <= 0 || C <= 0 || !ws) return UMI_ERR_BADARG;
+    for (int i = 0; i < n; ++i)
+        if (!xs[i] || !outs[i]) return UMI_ERR_BADARG;
+    if (ws_bytes < (size_t)(n < 16 ? n : 16) * umi_colsum_ws_bytes(M, C)) return UMI_ERR_WORKSPACE;
+    if (dtype != UMI_F16 || !umi_colsum_group_f16v(n, xs, ldx, outs, out_scale, (float*)ws, M, C, (hipStream_t)stream))
+        return UMI_ERR_UNSUPPORTED;
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
 extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, long M, int C, int dtype, void* ws,
                           size_t ws_bytes, umi_stream_t stream) {
     if (!x || !out || M <= 0 || C <= 0) return UMI_ERR_BADARG;

@@ -26,20 +26,25 @@ class TUTape(Tape):
         self._seed_dev = seed_dev         # int32 device scalar mixed into every dropout seed inside the kernel: a step replayed
         self._drop_count = 0              # from a captured HIP graph (host-side `seed` frozen) still draws fresh masks
         self._wstd_pending, self._wstd_flat = [], None
-        self._wgrad_groups, self._deferred_dy = {}, set()
+        self._wgrad_groups, self._readonly, self._colsum_groups = {}, set(), {}
 
     # gradients of a value with several consumers are summed by a libunetmi kernel (no torch arithmetic)
     def _give(self, act, g):
         if act.parts is None and act.needs_grad and act.grad is not None:
             act.gives += 1
-            if act.grad.data_ptr() in self._deferred_dy:       # a deferred weight gradient still reads this buffer
-                tgt = torch.empty_like(act.grad)
+            if act.grad.data_ptr() in self._readonly:       # another reader of this buffer is still to come: a deferred
+                tgt = torch.empty_like(act.grad)               # weight gradient, or the other addend of a residual add
                 ops_tu.add(act.grad, g, tgt)
                 act.grad = tgt
                 return
             ops_tu.add(act.grad, g, act.grad)
             return
         super()._give(act, g)
+
+    def _accumulate_target(self, act, src, R, S, stride, pad):
+        if act.grad is not None and act.grad.data_ptr() in self._readonly:
+            return None                                        # read-only buffer (see _give)
+        return super()._accumulate_target(act, src, R, S, stride, pad)
 
     # ---- weight gradients of the token linears, deferred to the end of the backward pass and run per SHAPE: one launch for
     # the twelve encoder layers' fc1 weights, one for fc2, ... (umi_conv_wgrad_group).  One layer at a time these GEMMs have
@@ -51,16 +56,29 @@ class TUTape(Tape):
             return False
         key = (tuple(x.shape), x.stride(), tuple(dy.shape), dy.stride(), s_co, s_ci)
         self._wgrad_groups.setdefault(key, []).append((x, dy, gw))
-        self._deferred_dy.add(dy.data_ptr())
+        self._readonly.add(dy.data_ptr())
+        return True
+
+    def _defer_colsum(self, dy, gb):
+        """Bias gradient = column sums of dy: with the weight gradient deferred, dy is alive until the end of the pass anyway."""
+        if dy.data_ptr() not in self._readonly:
+            return False
+        self._colsum_groups.setdefault((tuple(dy.shape), dy.stride()), []).append((dy, gb))
         return True
 
     def _flush_wgrad_groups(self):
+        for items in self._colsum_groups.values():
+            dys, gbs = zip(*items)
+            if len(items) < 2 or not ops.colsum_group(dys, gbs, self.inv):
+                for dy, gb in items:
+                    ops.colsum(dy, gb, self.inv)
+        self._colsum_groups = {}
         for (xs_, _, dys_, _, s_co, s_ci), items in self._wgrad_groups.items():
             xs, dys, gws = zip(*items)
             if len(items) < 2 or not ops.conv_wgrad_group(xs, dys, gws, s_co, s_ci, self.inv):
                 for x, dy, gw in items:
                     ops.conv_wgrad(x, None, dy, None, gw, s_co, s_ci, 1, self.inv, 1, 1, 1, 0)
-        self._wgrad_groups, self._deferred_dy = {}, set()
+        self._wgrad_groups, self._readonly, self._colsum_groups = {}, set(), {}
 
     # ---- convolution with weight standardisation (no bias), output stored raw == activated -----------------------
     def std_conv(self, a: Act, conv):
@@ -122,7 +140,7 @@ class TUTape(Tape):
 
     def backward(self):
         self._wstd_pending, self._wstd_flat = [], None
-        self._wgrad_groups, self._deferred_dy = {}, set()
+        self._wgrad_groups, self._readonly, self._colsum_groups = {}, set(), {}
         super().backward()
 
     def _finish_param_grads(self):
@@ -222,7 +240,8 @@ class TUTape(Tape):
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
-                    ops.colsum(o.grad, gb, self.inv)
+                    if id(bias) in self.param_grads or not self._defer_colsum(o.grad, gb):
+                        ops.colsum(o.grad, gb, self.inv)
                     self._set_pgrad(bias, gb)
                 if _wants_grad(a):
                     dx = self.alloc(N, H, W, Ci, device=out.device)
@@ -275,10 +294,11 @@ class TUTape(Tape):
             def bwd():
                 if o.grad is None:
                     return
-                # both addends receive the same gradient; the second gets its own copy so later in-place accumulation
-                # into one cannot alias the other
+                # both addends receive the same tensor (no copy): it is marked read-only, an accumulation into either
+                # addend's gradient then goes to a fresh tensor (_give) instead of in place
+                self._readonly.add(o.grad.data_ptr())
                 self._give(a, o.grad)
-                self._give(b, o.grad.clone())
+                self._give(b, o.grad)
             self.steps.append(bwd)
         return o
 
@@ -374,7 +394,8 @@ class TUTape(Tape):
                                                                                                  gw, C, 1):
                     ops.conv_wgrad(a.raw, a.tx, dqkv, None, gw, C, 1, 1, self.inv, 1, 1, 1, 0)
                 gb = torch.empty(3 * C, dtype=torch.float32, device=out.device)
-                ops.colsum(dqkv, gb, self.inv)
+                if any(id(m.bias) in self.param_grads for m in mods) or not self._defer_colsum(dqkv, gb):
+                    ops.colsum(dqkv, gb, self.inv)
                 for i, m in enumerate(mods):
                     self._set_pgrad(m.weight, gw[i * C:(i + 1) * C])
                     self._set_pgrad(m.bias, gb[i * C:(i + 1) * C])

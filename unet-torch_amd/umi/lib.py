@@ -69,6 +69,7 @@ SIGNATURES = {
                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p, c_size_t, c_void_p]),
     "umi_colsum_ws_bytes": (c_size_t, [c_long, c_int]),
+    "umi_colsum_group": (c_int, [c_int, c_void_p, c_int, c_void_p, c_float, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "umi_materialize_nchw": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "umi_wstd_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "umi_wstd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

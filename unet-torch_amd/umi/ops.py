@@ -653,6 +653,28 @@ def colsum(x, out, out_scale):
                                ws.numel(), _stream()), "umi_colsum")
 
 
+def colsum_group(xs, outs, out_scale):
+    """outs[i] <- out_scale * column sums of xs[i] for tensors of one shape, two launches per 16; False where the grouped
+    kernel does not apply (nothing was launched)."""
+    import ctypes
+    n = len(xs)
+    N, H, W, C, ldx = _nhwc(xs[0])
+    M = N * H * W
+    if xs[0].dtype != torch.float16 or C % 8 or ldx % 8:
+        return False
+    for x, o in zip(xs, outs):
+        assert _nhwc(x) == (N, H, W, C, ldx) and o.dtype == torch.float32 and o.numel() == C
+    ws = workspace(min(n, 16) * L.fn("umi_colsum_ws_bytes")(M, C), xs[0].device)
+    arr = ctypes.c_void_p * n
+    px, po = arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in outs])
+    st = L.fn("umi_colsum_group")(n, ctypes.cast(px, ctypes.c_void_p), ldx, ctypes.cast(po, ctypes.c_void_p), out_scale, M, C,
+                                  _dt(xs[0]), ws.data_ptr(), ws.numel(), _stream())
+    if st == -2:
+        return False
+    L.check(st, "umi_colsum_group")
+    return True
+
+
 def add2_relu(a, txa, b, txb, y):
     """y <- max(txa(a) + txb(b), 0)  (attention gate, reference Model.py:302)."""
     N, H, W, C, lda = _nhwc(a)
