@@ -215,9 +215,9 @@ int umi_wstd_bwd_multi(const void* descs, int n_desc, int total_rows, const floa
 /* GroupNorm (+ optional residual add, + optional ReLU) on NHWC, y = [relu](gn(x) [+ res]) (resnet_skip.py:47-58,68-73).
  * mean/rstd: [N*G] saved for backward.  Backward: dx (and dres = masked dy when dres != NULL), dgamma/dbeta scaled by
  * out_scale; `y` is the forward OUTPUT (ReLU mask).
- * tickets (backward): NULL, or >= N + 1 ints of device memory that are ZERO on entry, are left zero, and are not used by
- * anything running concurrently on another stream: the later reduction stages then run inside the last-arriving workgroups
- * of the first (fixed summation order; two launches instead of five). */
+ * part_out (backward): NULL, or [N][2][C] floats that receive the per-sample sums (dz*xhat, dz) per channel; dgamma / dbeta
+ * may then be NULL and are formed later for many layers at once by umi_gn_param_grads_group (parts / dgammas / dbetas: HOST
+ * arrays of n device pointers, Cs: n channel counts; out[c] = out_scale * sum over the N samples). */
 size_t umi_gn_fwd_ws_bytes(int N, long HW, int C);
 int umi_gn_fwd(const void* x, int ldx, const float* gamma, const float* beta, const void* res, int ldr, void* y, int ldy,
                float* mean, float* rstd, int relu, int N, long HW, int C, int G, float eps, int dtype,
@@ -226,7 +226,9 @@ size_t umi_gn_bwd_ws_bytes(int N, long HW, int C, int G);
 int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                const float* rstd, const float* gamma, int relu, void* dx, int lddx, void* dres, int lddr,
                float* dgamma, float* dbeta, float out_scale, int N, long HW, int C, int G, int dtype,
-               void* ws, size_t ws_bytes, int* tickets, umi_stream_t stream);
+               void* ws, size_t ws_bytes, float* part_out, umi_stream_t stream);
+int umi_gn_param_grads_group(int n, const float* const* parts, const int* Cs, int N, float* const* dgammas,
+                             float* const* dbetas, float out_scale, umi_stream_t stream);
 
 /* MaxPool2d(kernel 3, stride 2, pad 0) (resnet_skip.py:147) and its backward (first-max tie rule). */
 int umi_pool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, umi_stream_t stream);

@@ -410,7 +410,7 @@ int umi_conv3x3_mfma3(const void* x, int ldx, const void* tx, const void* wp8, v
     const long nblk = (long)N * tiles_x * tiles_y * n_co;
     static const int n_cu = [] {
         int dev = 0, v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
         return v > 0 ? v : 256;
     }();
     const int per_xcd = (int)((nblk + 7) / 8);

@@ -174,83 +174,6 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const half_t* __restrict
     }
 }
 
-// GroupNorm apply / backward apply, 8 channels per thread (all 8 in one group: Cg % 8 == 0)
-// UNI: the 8 channels of a thread lie in one group (Cg % 8 == 0); otherwise every channel looks up its own group
-template <bool UNI>
-__global__ __launch_bounds__(256) void gn_apply8_kernel(const half_t* __restrict__ x, int ldx, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, const half_t* __restrict__ res, int ldr,
-                                                        half_t* __restrict__ y, int ldy, int relu, int N, long HW, int C8,
-                                                        int G, int Cg) {
-    const long total = (long)N * HW * C8;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C8) * 8;
-        const long p = i / C8;
-        const int n = (int)(p / HW);
-        float m[8], r[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int sg = n * G + (c + (UNI ? 0 : j)) / Cg;
-            m[j] = mean[sg];
-            r[j] = rstd[sg];
-        }
-        half8 xv = *reinterpret_cast<const half8*>(x + p * ldx + c), rv, o;
-        if (res) rv = *reinterpret_cast<const half8*>(res + p * ldr + c);
-        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
-        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = ((float)xv[j] - m[j]) * r[j] * gg[j] + bb[j];
-            if (res) v += (float)rv[j];
-            if (relu) v = fmaxf(v, 0.f);
-            o[j] = (half_t)v;
-        }
-        *reinterpret_cast<half8*>(y + p * ldy + c) = o;
-    }
-}
-
-template <bool UNI>
-__global__ __launch_bounds__(256) void gn_bwd_apply8_kernel(const half_t* __restrict__ dy, int lddy, const half_t* __restrict__ y,
-                                                            int ldy, const half_t* __restrict__ x, int ldx,
-                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma, const float* __restrict__ gsum,
-                                                            int relu, half_t* __restrict__ dx, int lddx, half_t* __restrict__ dres,
-                                                            int lddr, int N, long HW, int C8, int G, int Cg) {
-    const float invm = 1.f / (float)(HW * Cg);
-    const long total = (long)N * HW * C8;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C8) * 8;
-        const long p = i / C8;
-        const int n = (int)(p / HW);
-        float m[8], r[8], q1[8], q2[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int sg = n * G + (c + (UNI ? 0 : j)) / Cg;
-            m[j] = mean[sg];
-            r[j] = rstd[sg];
-            q1[j] = gsum[sg * 2 + 0] * invm;
-            q2[j] = gsum[sg * 2 + 1] * invm;
-        }
-        half8 gv = *reinterpret_cast<const half8*>(dy + p * lddy + c);
-        half8 xv = *reinterpret_cast<const half8*>(x + p * ldx + c), yv, o, dz8;
-        if (relu) yv = *reinterpret_cast<const half8*>(y + p * ldy + c);
-        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
-        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float dz = (float)gv[j];
-            if (relu && !((float)yv[j] > 0.f)) dz = 0.f;
-            const float xh = ((float)xv[j] - m[j]) * r[j];
-            o[j] = (half_t)(r[j] * (dz * gg[j] - q1[j] - xh * q2[j]));
-            dz8[j] = (half_t)dz;
-        }
-        *reinterpret_cast<half8*>(dx + p * lddx + c) = o;
-        if (dres) *reinterpret_cast<half8*>(dres + p * lddr + c) = dz8;
-    }
-}
-
 }  // namespace
 
 bool umi_ew_f16v(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C, long bcast_rows,
@@ -387,38 +310,5 @@ bool umi_bilinear2x_f16v(const void* x, int ldx, const void* tx, void* y, int ld
     else
         hipLaunchKernelGGL(bilinear2x_bwd8_kernel, dim3(grid8((long)N * H * W * C8)), dim3(256), 0, s, (const half_t*)x, ldx,
                            (half_t*)y, ldy, N, H, W, C8);
-    return true;
-}
-
-bool umi_gn_apply_f16v(const void* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                       const void* res, int ldr, void* y, int ldy, int relu, int N, long HW, int C, int G, hipStream_t s) {
-    if (C % G || C % 8 || ldx % 8 || ldy % 8 || (res && ldr % 8) || !al16(x) || !al16(y) || (res && !al16(res)) ||
-        !al16(gamma) || !al16(beta))
-        return false;
-    const int C8 = C / 8;
-    if ((C / G) % 8 == 0)
-        hipLaunchKernelGGL(gn_apply8_kernel<true>, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd,
-                           gamma, beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C8, G, C / G);
-    else
-        hipLaunchKernelGGL(gn_apply8_kernel<false>, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd,
-                           gamma, beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C8, G, C / G);
-    return true;
-}
-
-bool umi_gn_bwd_apply_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
-                           const float* rstd, const float* gamma, const float* gsum, int relu, void* dx, int lddx, void* dres,
-                           int lddr, int N, long HW, int C, int G, hipStream_t s) {
-    if (C % G || C % 8 || lddy % 8 || ldy % 8 || ldx % 8 || lddx % 8 || (dres && lddr % 8) || !al16(dy) || !al16(y) ||
-        !al16(x) || !al16(dx) || (dres && !al16(dres)) || !al16(gamma))
-        return false;
-    const int C8 = C / 8;
-    if ((C / G) % 8 == 0)
-        hipLaunchKernelGGL(gn_bwd_apply8_kernel<true>, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)dy, lddy,
-                           (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx,
-                           (half_t*)dres, lddr, N, HW, C8, G, C / G);
-    else
-        hipLaunchKernelGGL(gn_bwd_apply8_kernel<false>, dim3(grid8((long)N * HW * C8)), dim3(256), 0, s, (const half_t*)dy, lddy,
-                           (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx,
-                           (half_t*)dres, lddr, N, HW, C8, G, C / G);
     return true;
 }

@@ -599,11 +599,13 @@ __global__ void bilinear2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __r
 void umi_launch_reduce_rows2(const float* ws, int rows, int C, float* out0, float* out1, float scale, hipStream_t s);
 // groupnorm_f16.hip
 int umi_gn_splits(int N, long HW);
-bool umi_gn_stats_f16v(const void* x, int ldx, int N, long HW, int C, int G, float eps, float* mean, float* rstd, float* ws,
-                       hipStream_t s);
-bool umi_gn_bwd_reduce_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
-                            const float* rstd, const float* gamma, int relu, int N, long HW, int C, int G, float* gsum,
-                            float* part, float* ws, int* tickets, float* dgamma, float* dbeta, float out_scale, hipStream_t s);
+bool umi_gn_fwd_f16v(const void* x, int ldx, const float* gamma, const float* beta, const void* res, int ldr, void* y, int ldy,
+                     float* mean, float* rstd, int relu, int N, long HW, int C, int G, float eps, float* ws, hipStream_t s);
+bool umi_gn_bwd_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
+                     const float* rstd, const float* gamma, int relu, void* dx, int lddx, void* dres, int lddr, int N, long HW,
+                     int C, int G, float* part, float* ws, hipStream_t s);
+void umi_gn_param_grads_launch(int n, const float* const* parts, const int* Cs, int N, float* const* dgammas, float* const* dbetas,
+                               float scale, hipStream_t s);
 // elementwise_tu_f16.hip
 bool umi_ew_f16v(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C, long bcast_rows,
                  hipStream_t s);
@@ -612,11 +614,6 @@ bool umi_dropout_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int 
 int umi_ln_bwd_rows_f16v();
 bool umi_ln_bwd_f16v(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
                      void* dx, int lddx, float* part, long M, int C, hipStream_t s);
-bool umi_gn_apply_f16v(const void* x, int ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                       const void* res, int ldr, void* y, int ldy, int relu, int N, long HW, int C, int G, hipStream_t s);
-bool umi_gn_bwd_apply_f16v(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
-                           const float* rstd, const float* gamma, const float* gsum, int relu, void* dx, int lddx, void* dres,
-                           int lddr, int N, long HW, int C, int G, hipStream_t s);
 bool umi_bilinear2x_f16v(const void* x, int ldx, const void* tx, void* y, int ldy, int backward, int N, int H, int W, int C,
                          hipStream_t s);
 // attention_mfma.hip
@@ -669,12 +666,7 @@ extern "C" int umi_gn_fwd(const void* x, int ldx, const float* gamma, const floa
     hipStream_t s = (hipStream_t)st;
     const int grid = grid_for((long)N * HW * C);
     if (dtype == UMI_F16 && ws && ws_bytes >= umi_gn_fwd_ws_bytes(N, HW, C) &&
-        umi_gn_stats_f16v(x, ldx, N, HW, C, G, eps, mean, rstd, (float*)ws, s)) {
-        if (umi_gn_apply_f16v(x, ldx, mean, rstd, gamma, beta, res, ldr, y, ldy, relu, N, HW, C, G, s)) {
-            UMI_LAUNCH_CHECK();
-            return UMI_OK;
-        }
-        hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, mean, rstd, gamma, beta, (const half_t*)res, ldr, (half_t*)y, ldy, relu, N, HW, C, G);
+        umi_gn_fwd_f16v(x, ldx, gamma, beta, res, ldr, y, ldy, mean, rstd, relu, N, HW, C, G, eps, (float*)ws, s)) {
         UMI_LAUNCH_CHECK();
         return UMI_OK;
     }
@@ -694,21 +686,18 @@ extern "C" size_t umi_gn_bwd_ws_bytes(int N, long HW, int C, int G) {
 extern "C" int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx, const float* mean,
                           const float* rstd, const float* gamma, int relu, void* dx, int lddx, void* dres, int lddr,
                           float* dgamma, float* dbeta, float out_scale, int N, long HW, int C, int G, int dtype, void* ws,
-                          size_t ws_bytes, int* tickets, umi_stream_t st) {
-    if (!dy || !y || !x || !dx || !dgamma || !dbeta || !ws || C % G) return UMI_ERR_BADARG;
+                          size_t ws_bytes, float* part_out, umi_stream_t st) {
+    if (!dy || !y || !x || !dx || !ws || C % G || (!part_out && (!dgamma || !dbeta))) return UMI_ERR_BADARG;
     if (ws_bytes < umi_gn_bwd_ws_bytes(N, HW, C, G)) return UMI_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)st;
     float* gsum = (float*)ws;
-    float* part = gsum + (size_t)N * G * 2;
-    float* stage1 = part + (size_t)N * 2 * C;
+    float* part = part_out ? part_out : gsum + (size_t)N * G * 2;
+    float* stage1 = gsum + (size_t)N * G * 2 + (size_t)N * 2 * C;
     const int grid = grid_for((long)N * HW * C);
-    if (N >= 1024) tickets = nullptr;
-    if (dtype == UMI_F16 && umi_gn_bwd_reduce_f16v(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, relu, N, HW, C, G, gsum, part,
-                                                    stage1, tickets, dgamma, dbeta, out_scale, s)) {
-        if (!umi_gn_bwd_apply_f16v(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, gsum, relu, dx, lddx, dres, lddr, N, HW, C, G, s))
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx, (half_t*)dres, lddr, N, HW, C, G);
+    if (dtype == UMI_F16 &&
+        umi_gn_bwd_f16v(dy, lddy, y, ldy, x, ldx, mean, rstd, gamma, relu, dx, lddx, dres, lddr, N, HW, C, G, part, stage1, s)) {
         UMI_LAUNCH_CHECK();
-        if (!tickets) {                  // (with tickets the reduction kernel's last workgroup has written dgamma / dbeta)
+        if (dgamma && dbeta) {           // (a caller that keeps the per-sample rows may sum them later: umi_gn_param_grads_group)
             umi_launch_reduce_rows2(part, N, C, dgamma, dbeta, out_scale, s);
             UMI_LAUNCH_CHECK();
         }
@@ -720,7 +709,20 @@ extern "C" int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, cons
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<half_t>, dim3(N * G), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, relu, HW, C, G, gsum, part);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)dy, lddy, (const half_t*)y, ldy, (const half_t*)x, ldx, mean, rstd, gamma, gsum, relu, (half_t*)dx, lddx, (half_t*)dres, lddr, N, HW, C, G))
     UMI_LAUNCH_CHECK();
-    umi_launch_reduce_rows2(part, N, C, dgamma, dbeta, out_scale, s);
+    if (dgamma && dbeta) {
+        umi_launch_reduce_rows2(part, N, C, dgamma, dbeta, out_scale, s);
+        UMI_LAUNCH_CHECK();
+    }
+    return UMI_OK;
+}
+
+// dgamma / dbeta of n GroupNorm layers from the per-sample rows umi_gn_bwd left in part_out, one launch per 16 layers
+extern "C" int umi_gn_param_grads_group(int n, const float* const* parts, const int* Cs, int N, float* const* dgammas,
+                                        float* const* dbetas, float out_scale, umi_stream_t st) {
+    if (n <= 0 || !parts || !Cs || !dgammas || !dbetas || N <= 0) return UMI_ERR_BADARG;
+    for (int i = 0; i < n; ++i)
+        if (!parts[i] || !dgammas[i] || !dbetas[i] || Cs[i] <= 0) return UMI_ERR_BADARG;
+    umi_gn_param_grads_launch(n, parts, Cs, N, dgammas, dbetas, out_scale, (hipStream_t)st);
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }

@@ -27,6 +27,7 @@ class TUTape(Tape):
         self._drop_count = 0              # from a captured HIP graph (host-side `seed` frozen) still draws fresh masks
         self._wstd_pending, self._wstd_flat = [], None
         self._wgrad_groups, self._readonly, self._colsum_groups = {}, set(), {}
+        self._gn_pending = []
 
     # gradients of a value with several consumers are summed by a libunetmi kernel (no torch arithmetic)
     def _give(self, act, g):
@@ -145,6 +146,13 @@ class TUTape(Tape):
 
     def _finish_param_grads(self):
         self._flush_wgrad_groups()
+        by_n = {}
+        for part, n_, dg, db in self._gn_pending:
+            by_n.setdefault(n_, []).append((part, dg, db))
+        for n_, items in by_n.items():
+            parts, dgs, dbs = zip(*items)
+            ops_tu.gn_param_grads_group(parts, n_, dgs, dbs, self.inv)
+        self._gn_pending = []
         if self._wstd_pending:
             self.pack_cache.wstd_bwd(self._wstd_pending, *self._wstd_flat)
             self._wstd_pending = []
@@ -179,7 +187,16 @@ class TUTape(Tape):
                     return
                 dx = self.alloc(N, H, W, C, device=out.device)
                 dres = self.alloc(N, H, W, C, device=out.device) if (residual is not None and _wants_grad(residual)) else None
-                dg, db = ops_tu.gn_bwd(o.grad, out, a.raw, mean, rstd, g32, gn.num_groups, relu, dx, dres, self.inv)
+                if (self.grad_sink is None and self.dtype == torch.float16 and id(gn.weight) not in self.param_grads
+                        and id(gn.bias) not in self.param_grads):
+                    # dgamma / dbeta of all GroupNorm layers are summed from their per-sample rows at the end of the pass
+                    part = ops_tu.gn_bwd(o.grad, out, a.raw, mean, rstd, g32, gn.num_groups, relu, dx, dres, self.inv,
+                                         keep_part=True)
+                    dg, db = torch.empty(C, dtype=torch.float32, device=out.device), torch.empty(C, dtype=torch.float32,
+                                                                                                  device=out.device)
+                    self._gn_pending.append((part, N, dg, db))
+                else:
+                    dg, db = ops_tu.gn_bwd(o.grad, out, a.raw, mean, rstd, g32, gn.num_groups, relu, dx, dres, self.inv)
                 self._set_pgrad(gn.weight, dg)
                 self._set_pgrad(gn.bias, db)
                 if dres is not None:

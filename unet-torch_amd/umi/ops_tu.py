@@ -11,22 +11,6 @@ def _rows(t):
     return N * H * W, C, ld
 
 
-_tickets = {}
-
-
-def tickets(device):
-    """Zeroed counters for the kernels that fold their last reduction stage into the last-arriving workgroups (they leave
-    them zero): one buffer per device + stream.  UMI_NO_TICKETS=1: None (separate second-stage launches; A/B knob)."""
-    import os
-    if os.environ.get("UMI_NO_TICKETS") == "1":
-        return None
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    t = _tickets.get(key)
-    if t is None:
-        t = _tickets[key] = torch.zeros(4096, dtype=torch.int32, device=device)
-    return t
-
-
 def wstd_fwd(w, eps=1e-5):
     Co = w.shape[0]
     K = w[0].numel()
@@ -58,16 +42,32 @@ def gn_fwd(x, gamma, beta, groups, eps, relu, res, y):
     return mean, rstd
 
 
-def gn_bwd(dy, y, x, mean, rstd, gamma, groups, relu, dx, dres, out_scale):
+def gn_bwd(dy, y, x, mean, rstd, gamma, groups, relu, dx, dres, out_scale, keep_part=False):
+    """keep_part: dgamma / dbeta are NOT computed; returns the per-sample rows [N][2][C] for gn_param_grads_group instead."""
     N, H, W, C, ldx = _nhwc(x)
-    dg = torch.empty(C, dtype=torch.float32, device=x.device)
-    db = torch.empty_like(dg)
     ws = workspace(L.fn("umi_gn_bwd_ws_bytes")(N, H * W, C, groups), x.device)
+    if keep_part:
+        part, dg, db = torch.empty(N * 2 * C, dtype=torch.float32, device=x.device), None, None
+    else:
+        part, dg = None, torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
     L.check(L.fn("umi_gn_bwd")(dy.data_ptr(), _nhwc(dy)[4], y.data_ptr(), _nhwc(y)[4], x.data_ptr(), ldx, mean.data_ptr(),
                                rstd.data_ptr(), gamma.data_ptr(), int(relu), dx.data_ptr(), _nhwc(dx)[4], _ptr(dres),
-                               _nhwc(dres)[4] if dres is not None else 0, dg.data_ptr(), db.data_ptr(), out_scale, N, H * W,
-                               C, groups, _dt(x), ws.data_ptr(), ws.numel(), _ptr(tickets(x.device)), _stream()), "umi_gn_bwd")
-    return dg, db
+                               _nhwc(dres)[4] if dres is not None else 0, _ptr(dg), _ptr(db), out_scale, N, H * W,
+                               C, groups, _dt(x), ws.data_ptr(), ws.numel(), _ptr(part), _stream()), "umi_gn_bwd")
+    return part if keep_part else (dg, db)
+
+
+def gn_param_grads_group(parts, N, dgammas, dbetas, out_scale):
+    """dgammas[i] / dbetas[i] <- out_scale * sum over the N samples of parts[i] ([N][2][C_i]): one launch per 16 layers."""
+    import ctypes
+    n = len(parts)
+    arr = ctypes.c_void_p * n
+    pp, pg, pb = (arr(*[t.data_ptr() for t in ts]) for ts in (parts, dgammas, dbetas))
+    cs = (ctypes.c_int * n)(*[t.numel() for t in dgammas])
+    L.check(L.fn("umi_gn_param_grads_group")(n, ctypes.cast(pp, ctypes.c_void_p), ctypes.cast(cs, ctypes.c_void_p), N,
+                                             ctypes.cast(pg, ctypes.c_void_p), ctypes.cast(pb, ctypes.c_void_p), out_scale,
+                                             _stream()), "umi_gn_param_grads_group")
 
 
 def pool3s2_fwd(x, y):
