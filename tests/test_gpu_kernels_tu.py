@@ -514,7 +514,7 @@ def test_grouped_pointwise_wgrad_matches_per_layer_launches(n, M, Ci, Co, stride
 @pytest.mark.parametrize("n,M,C,strided", [(12, 4704, 3072, False), (18, 333, 72, False), (3, 1000, 768, True)])
 def test_grouped_colsum_matches_per_tensor_launches(n, M, C, strided):
     """umi_colsum_group (bias gradients of n same-shaped layers, two launches per 16) against umi_colsum per tensor: the same
-    partial-row kernel body and the same fp64 second stage, so the results are identical."""
+    partial-row kernel body, fp64 second stages that differ only in summation order."""
     lib, ops, T = _gpu()
     g = torch.Generator().manual_seed(n + M + C)
     pad = 64 if strided else 0
@@ -524,5 +524,5 @@ def test_grouped_colsum_matches_per_tensor_launches(n, M, C, strided):
     for x, o in zip(xs, outs):
         one = torch.empty(C, device=DEV)
         ops.colsum(x, one, 0.5)
-        assert torch.equal(o, one)
+        _close(o, one, 1e-6)
         _close(o, x[0, 0].float().sum(0) * 0.5, 2e-3)

@@ -10,6 +10,7 @@
 // workgroup writes back the whole L2: 21.1 -> 27.9 ms per TransUNet step.)
 // The generic kernels in transformer_kernels.hip (one (sample, group) per workgroup, pixel-strided) remain for other shapes.
 #include "common.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
@@ -23,7 +24,7 @@ static int gn_rows(int N, long HW) {
     return (int)(r < 16 ? 16 : (r > 1024 ? 1024 : r));
 }
 
-// MODE 0: out = (sum x, sum x^2) per channel.   MODE 1: out = (sum dz*xhat, sum dz) per channel, dz = dy*[y>0 | 1]
+// MODE 0: out = (sum (x - shift), sum (x - shift)^2) per channel.   MODE 1: out = (sum dz*xhat, sum dz) per channel, dz = dy*[y>0 | 1]
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_rowsum_v8(const half_t* __restrict__ x, int ldx, const half_t* __restrict__ dy,
                                                     int lddy, const half_t* __restrict__ y, int ldy,
@@ -38,9 +39,15 @@ __global__ __launch_bounds__(256) void gn_rowsum_v8(const half_t* __restrict__ x
     long r1 = r0 + ROWS;
     if (r1 > HW) r1 = HW;
     float a[8], b[8], mu[8], rs[8];
+    // MODE 0 sums x - shift, shift = this channel's value at the sample's first pixel (the same for every row block of the
+    // sample; gn_apply_fin_kernel re-reads it): a channel whose |mean| is large against its spread -- the per-channel groups of
+    // the projection shortcuts' GroupNorm(C, C) -- would otherwise lose its variance in sum(x^2) - sum(x)^2 / n at fp32
+    half8 sh8;
+    if (MODE == 0) sh8 = *reinterpret_cast<const half8*>(x + (long)n * HW * ldx + cg * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         a[j] = b[j] = 0.f;
+        if (MODE == 0) mu[j] = (float)sh8[j];
         if (MODE == 1) {
             int g = (cg * 8 + j) / (C / G);
             mu[j] = mean[n * G + g];
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(256) void gn_rowsum_v8(const half_t* __restrict__ x
     }
 #define UMI_GN_ACC(xv_, gv_, yv_)                                                                                  \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
-        if (MODE == 0) { float f = (float)xv_[j]; a[j] += f; b[j] = fmaf(f, f, b[j]); }                           \
+        if (MODE == 0) { float f = (float)xv_[j] - mu[j]; a[j] += f; b[j] = fmaf(f, f, b[j]); }                   \
         else {                                                                                                    \
             float dz = (float)gv_[j];                                                                             \
             if (relu && !((float)yv_[j] > 0.f)) dz = 0.f;                                                         \
@@ -102,8 +109,9 @@ __global__ __launch_bounds__(256) void gn_apply_fin_kernel(const half_t* __restr
                                                            const float* __restrict__ beta, const half_t* __restrict__ res, int ldr,
                                                            half_t* __restrict__ y, int ldy, int relu, long HW, int C, int G,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int ROWS) {
-    __shared__ double chs[2][2048];                    // per-channel sums over the row blocks (C <= 2048: shape_ok)
-    __shared__ float gm[256], gr[256];                 // per-group mean / rstd (G <= 256)
+    __shared__ double chs[2][1024];                    // per-channel sums over the row blocks (C <= 1024: shape_ok)
+    __shared__ float shf[1024];                        // per-channel shift of those sums (see gn_rowsum_v8)
+    __shared__ float gm[1024], gr[1024];               // per-group mean / rstd (G <= C: the projection shortcuts' GroupNorm(C, C))
     const int tid = threadIdx.x, n = blockIdx.x, Cg = C / G;
     for (int c = tid; c < C; c += 256) {
         double sm = 0.0, q = 0.0;
@@ -114,14 +122,20 @@ __global__ __launch_bounds__(256) void gn_apply_fin_kernel(const half_t* __restr
         }
         chs[0][c] = sm;
         chs[1][c] = q;
+        shf[c] = (float)x[(long)n * HW * ldx + c];
     }
     __syncthreads();
     for (int g = tid; g < G; g += 256) {
-        double sm = 0.0, q = 0.0;
-        for (int c = g * Cg; c < (g + 1) * Cg; ++c) { sm += chs[0][c]; q += chs[1][c]; }
         const double cnt = (double)HW * Cg;
+        double sm = 0.0;
+        for (int c = g * Cg; c < (g + 1) * Cg; ++c) sm += chs[0][c] + (double)HW * (double)shf[c];
         const double m = sm / cnt;
-        double var = q / cnt - m * m;
+        double q = 0.0;                                 // sum_p (x - m)^2 = S2 - 2 d S1 + HW d^2 per channel, d = m - shift
+        for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
+            const double d = m - (double)shf[c];
+            q += chs[1][c] - 2.0 * d * chs[0][c] + (double)HW * d * d;
+        }
+        double var = q / cnt;
         if (var < 0.0) var = 0.0;
         const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
         gm[g] = mf;
@@ -184,8 +198,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_fin_kernel(const half_t* __r
                                                                const float* __restrict__ gamma, const float* __restrict__ ws, int S,
                                                                int relu, half_t* __restrict__ dx, int lddx, half_t* __restrict__ dres,
                                                                int lddr, long HW, int C, int G, float* __restrict__ part, int ROWS) {
-    __shared__ float chs[2][2048];
-    __shared__ float gq[2][256];
+    __shared__ float chs[2][1024];
+    __shared__ float gq[2][1024];
     const int tid = threadIdx.x, n = blockIdx.x, Cg = C / G;
     for (int i = tid; i < 2 * C; i += 256) {
         const int which = i / C, c = i - which * C;
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(256) void gn_param_grads_kernel(GnPg t, int N, floa
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 bool shape_ok(int C, int G) {
-    if (C % 8 || C % G || G > 256) return false;
+    if (C % 8 || C % G || C > 1024) return false;           // (LDS tables of the apply kernels' prologues)
     const int G8 = C / 8;
     return G8 <= 256 && 256 % G8 == 0;
 }
