@@ -230,10 +230,14 @@ int umi_gn_bwd(const void* dy, int lddy, const void* y, int ldy, const void* x, 
 int umi_gn_param_grads_group(int n, const float* const* parts, const int* Cs, int N, float* const* dgammas,
                              float* const* dbetas, float out_scale, umi_stream_t stream);
 
-/* MaxPool2d(kernel 3, stride 2, pad 0) (resnet_skip.py:147) and its backward (first-max tie rule). */
-int umi_pool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, umi_stream_t stream);
-int umi_pool3s2_bwd(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx, int N, int H, int W, int C,
-                    int dtype, umi_stream_t stream);
+/* MaxPool2d(kernel 3, stride 2, pad 0) (resnet_skip.py:147) and its backward (first-max tie rule).
+ * idx: NULL, or N*Ho*Wo*C bytes (8-byte aligned, fp16 with C % 8 == 0 only: UMI_ERR_UNSUPPORTED otherwise) in which the forward
+ * records the winning tap 0..8 of every output element; a backward given the same buffer reads it instead of re-deriving
+ * every window's maximum from the input. */
+int umi_pool3s2_fwd(const void* x, int ldx, void* y, int ldy, void* idx, int N, int H, int W, int C, int dtype,
+                    umi_stream_t stream);
+int umi_pool3s2_bwd(const void* dy, int lddy, const void* x, int ldx, const void* idx, void* dx, int lddx, int N, int H, int W,
+                    int C, int dtype, umi_stream_t stream);
 
 /* LayerNorm over the last dim (vit_seg_modeling.py:172-173,232; eps 1e-6) and backward. */
 int umi_ln_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean, float* rstd,

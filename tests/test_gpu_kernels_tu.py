@@ -526,3 +526,63 @@ def test_grouped_colsum_matches_per_tensor_launches(n, M, C, strided):
         ops.colsum(x, one, 0.5)
         _close(o, one, 1e-6)
         _close(o, x[0, 0].float().sum(0) * 0.5, 2e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 15, 17, 64), (1, 112, 112, 64), (3, 8, 9, 24)])
+def test_pool3s2_fp16_with_recorded_taps(shape):
+    """MaxPool2d(3, 2) fp16 vector kernels: forward against torch (ties included: values drawn from 8 levels), backward with the
+    recorded winning taps against the backward that re-derives them from the input -- identical, and both equal to torch's
+    max_pool2d gradient (first maximum in scan order)."""
+    lib, ops, T = _gpu()
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randint(0, 8, (N, H, W, C), generator=g).float() * 0.25 - 1.0).half()
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    dy = torch.randn(N, Ho, Wo, C, generator=g).half()
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 0)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    y = torch.empty(N, Ho, Wo, C, device=DEV, dtype=torch.float16)
+    idx = torch.full((N, Ho, Wo, C), 255, dtype=torch.uint8, device=DEV)
+    T.pool3s2_fwd(xd, y, idx)
+    assert torch.equal(y.cpu().float().permute(0, 3, 1, 2), ref.detach())
+    assert int(idx.max()) <= 8
+    dx_a = torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+    dx_b = torch.empty_like(dx_a)
+    T.pool3s2_bwd(dyd, xd, dx_a, idx)
+    T.pool3s2_bwd(dyd, xd, dx_b, None)
+    assert torch.equal(dx_a, dx_b)
+    _close(dx_a.permute(0, 3, 1, 2), xr.grad, 2e-3)
+
+
+def test_group_norm_per_channel_groups_and_deferred_param_grads():
+    """GroupNorm(C, C) (the projection shortcuts, resnet_skip.py:62-63: one channel per group, instance-norm-like) on channels
+    whose mean is 50x their spread -- the case the shifted statistics exist for -- and dgamma / dbeta formed later from the
+    per-sample rows (umi_gn_param_grads_group) against the immediate ones."""
+    lib, ops, T = _gpu()
+    N, H, W, C, G = 3, 14, 14, 512, 512
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(N, H, W, C, generator=g) * 0.1 + 5.0 * torch.randn(1, 1, 1, C, generator=g)).half()
+    gamma, beta = 0.5 + torch.rand(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy = torch.randn(N, H, W, C, generator=g).half()
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.group_norm(xr, G, gr, br, 1e-5)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    xd, y = x.to(DEV), torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+    mean, rstd = T.gn_fwd(xd, gamma.to(DEV), beta.to(DEV), G, 1e-5, False, None, y)
+    want_rstd = 1.0 / torch.sqrt(x.float().var(dim=(1, 2), unbiased=False) + 1e-5)
+    assert ((rstd.cpu().view(N, C) - want_rstd).abs() / want_rstd).max().item() < 1e-4
+    _close(y.permute(0, 3, 1, 2), ref, 4e-3)
+    dx = torch.empty_like(y)
+    dg, db = T.gn_bwd(dy.to(DEV), y, xd, mean, rstd, gamma.to(DEV), G, False, dx, None, 0.5)
+    dx2 = torch.empty_like(y)
+    part = T.gn_bwd(dy.to(DEV), y, xd, mean, rstd, gamma.to(DEV), G, False, dx2, None, 0.5, keep_part=True)
+    dg2, db2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    T.gn_param_grads_group([part], N, [dg2], [db2], 0.5)
+    assert torch.equal(dx, dx2)
+    _close(dg2, dg, 1e-6)
+    _close(db2, db, 1e-6)
+    _close(db, br.grad * 0.5, 2e-3)
+    _close(dg, gr.grad * 0.5, 2e-2)

@@ -609,6 +609,8 @@ void umi_gn_param_grads_launch(int n, const float* const* parts, const int* Cs, 
 // elementwise_tu_f16.hip
 bool umi_ew_f16v(int mode, const void* x, int ldx, const void* g, int ldg, void* y, int ldy, long M, int C, long bcast_rows,
                  hipStream_t s);
+bool umi_pool3s2_fwd_f16v(const void* x, int ldx, void* y, int ldy, void* idx, int N, int H, int W, int C, hipStream_t s);
+bool umi_pool3s2_bwd_f16v(const void* dy, int lddy, const void* idx, void* dx, int lddx, int N, int H, int W, int C, hipStream_t s);
 bool umi_dropout_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
                       const void* tx, const unsigned* seed_dev, hipStream_t s);
 int umi_ln_bwd_rows_f16v();
@@ -727,8 +729,14 @@ extern "C" int umi_gn_param_grads_group(int n, const float* const* parts, const 
     return UMI_OK;
 }
 
-extern "C" int umi_pool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, umi_stream_t st) {
+extern "C" int umi_pool3s2_fwd(const void* x, int ldx, void* y, int ldy, void* idx, int N, int H, int W, int C, int dtype,
+                               umi_stream_t st) {
     if (!x || !y || H < 3 || W < 3) return UMI_ERR_BADARG;
+    if (dtype == UMI_F16 && umi_pool3s2_fwd_f16v(x, ldx, y, ldy, idx, N, H, W, C, (hipStream_t)st)) {
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
+    if (idx) return UMI_ERR_UNSUPPORTED;           // only the vectorised fp16 kernel records the winning taps
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int grid = grid_for((long)N * Ho * Wo * C);
     DT_SWITCH(dtype,
@@ -737,9 +745,13 @@ extern "C" int umi_pool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, 
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }
-extern "C" int umi_pool3s2_bwd(const void* dy, int lddy, const void* x, int ldx, void* dx, int lddx, int N, int H, int W, int C,
-                               int dtype, umi_stream_t st) {
+extern "C" int umi_pool3s2_bwd(const void* dy, int lddy, const void* x, int ldx, const void* idx, void* dx, int lddx, int N, int H,
+                               int W, int C, int dtype, umi_stream_t st) {
     if (!dy || !x || !dx || H < 3 || W < 3) return UMI_ERR_BADARG;
+    if (idx && dtype == UMI_F16 && umi_pool3s2_bwd_f16v(dy, lddy, idx, dx, lddx, N, H, W, C, (hipStream_t)st)) {
+        UMI_LAUNCH_CHECK();
+        return UMI_OK;
+    }
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int grid = grid_for((long)N * H * W * C);
     DT_SWITCH(dtype,

@@ -208,14 +208,17 @@ class TUTape(Tape):
     def pool3s2(self, a: Act):
         N, H, W, C = a.shape
         out = self.alloc(N, (H - 3) // 2 + 1, (W - 3) // 2 + 1, C, device=a.raw.device)
-        ops_tu.pool3s2_fwd(a.raw, out)
+        idx = None
+        if self.record and self.dtype == torch.float16 and C % 8 == 0 and a.raw.stride(2) % 8 == 0:
+            idx = torch.empty(out.shape, dtype=torch.uint8, device=out.device)      # winning taps, for the backward
+        ops_tu.pool3s2_fwd(a.raw, out, idx)
         o = Act(out, None)
         if self.record:
             def bwd():
                 if o.grad is None or not _wants_grad(a):
                     return
                 dx = self.alloc(N, H, W, C, device=out.device)
-                ops_tu.pool3s2_bwd(o.grad, a.raw, dx)
+                ops_tu.pool3s2_bwd(o.grad, a.raw, dx, idx)
                 self._give(a, dx)
             self.steps.append(bwd)
         return o

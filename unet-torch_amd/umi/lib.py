@@ -83,8 +83,9 @@ SIGNATURES = {
                            c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_int, c_long, c_int, c_int, c_int,
                            c_void_p, c_size_t, c_void_p, c_void_p]),
     "umi_gn_param_grads_group": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p]),
-    "umi_pool3s2_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "umi_pool3s2_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_pool3s2_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_pool3s2_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_void_p]),
     "umi_ln_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_int, c_float,
                            c_int, c_void_p]),
     "umi_ln_bwd_ws_bytes": (c_size_t, [c_long, c_int]),

@@ -70,16 +70,17 @@ def gn_param_grads_group(parts, N, dgammas, dbetas, out_scale):
                                              _stream()), "umi_gn_param_grads_group")
 
 
-def pool3s2_fwd(x, y):
+def pool3s2_fwd(x, y, idx=None):
+    """idx: optional uint8 tensor [N,Ho,Wo,C] receiving the winning tap of every output element (fp16, C % 8 == 0)."""
     N, H, W, C, ldx = _nhwc(x)
-    L.check(L.fn("umi_pool3s2_fwd")(x.data_ptr(), ldx, y.data_ptr(), _nhwc(y)[4], N, H, W, C, _dt(x), _stream()),
+    L.check(L.fn("umi_pool3s2_fwd")(x.data_ptr(), ldx, y.data_ptr(), _nhwc(y)[4], _ptr(idx), N, H, W, C, _dt(x), _stream()),
             "umi_pool3s2_fwd")
 
 
-def pool3s2_bwd(dy, x, dx):
+def pool3s2_bwd(dy, x, dx, idx=None):
     N, H, W, C, ldx = _nhwc(x)
-    L.check(L.fn("umi_pool3s2_bwd")(dy.data_ptr(), _nhwc(dy)[4], x.data_ptr(), ldx, dx.data_ptr(), _nhwc(dx)[4], N, H, W, C,
-                                    _dt(x), _stream()), "umi_pool3s2_bwd")
+    L.check(L.fn("umi_pool3s2_bwd")(dy.data_ptr(), _nhwc(dy)[4], x.data_ptr(), ldx, _ptr(idx), dx.data_ptr(), _nhwc(dx)[4],
+                                    N, H, W, C, _dt(x), _stream()), "umi_pool3s2_bwd")
 
 
 def ln_fwd(x, gamma, beta, eps, y):
