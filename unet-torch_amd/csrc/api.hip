@@ -254,8 +254,10 @@ extern "C" int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* 
         return umi_head_fwd(x, ldx, tx, wp, bias, y, ldy, stat_part, (long)N * H * W, Ci, Co, out_dtype, (hipStream_t)stream);
     if (!stat_part && umi_smallk_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias))
         return umi_smallk_fwd(x, ldx, wp, y, ldy, (long)N * H * W, Ci, Co, (hipStream_t)stream);
-    if (!stat_part && umi_root_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias))
-        return umi_root_fwd(x, ldx, wp, y, ldy, N, H, W, Ho, Wo, Co, (hipStream_t)stream);
+    if (!stat_part && umi_root_fwd_ok(Ci, Co, R, S, stride, pad, ldy, in_dtype, out_dtype, flags, tx, bias)) {
+        const int st = umi_root_fwd(x, ldx, wp, y, ldy, N, H, W, Ho, Wo, Co, (hipStream_t)stream);
+        if (st != UMI_ERR_UNSUPPORTED) return st;          // (rows too wide for its LDS staging: the generic kernel below)
+    }
     if (!stat_part && umi_head3_fwd_ok(Ci, Co, R, S, stride, pad, ldx, in_dtype, out_dtype, flags))
         return umi_head3_fwd(x, ldx, tx, wp, bias, y, ldy, N, H, W, Ci, Co, (hipStream_t)stream);
     UMI_TRACE("fwd");

@@ -16,71 +16,99 @@ void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int 
 
 namespace {
 
-constexpr int ROOT_PPB = 512;        // output pixels per workgroup (root forward)
-constexpr int WG_PPB = 2048;         // output pixels per workgroup (weight-gradient kernels)
+constexpr int ROOT_ROWS = 4;         // output rows per workgroup (root forward: amortises the 37-KB weight staging)
+constexpr int ROOT_WROWS = 8;        // output rows per workgroup (root weight gradient)
+constexpr int WG_PPB = 2048;         // output pixels per workgroup (head weight-gradient kernel)
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 bool groups_ok(int C) { return C % 8 == 0 && C / 8 <= 64 && (256 % (C / 8)) == 0; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // root forward: y[n][ho][wo][co] = sum_{ty,tx,ci} x[n][S*ho+ty-PAD][S*wo+tx-PAD][ci] * w[(ty*R+tx)*CI + ci][co]
+// Workgroup = ROOT_ROWS output rows of one image.  The R input rows an output row reads are staged in LDS once (zero-padded
+// left / right / outside the image: no bounds checks in the tap loop), the weights once per workgroup as fp32; thread =
+// 8 output channels x 4 output pixels (wo = lane, lane + PL, ...): per tap 2 weight reads + 4 input reads for 32 FMAs.
+// (The first version read every input value from global memory, 2 bytes at a time, inside the tap loop: one memory round trip
+// per tap row, 207 us for the 24 x 112 x 112 x 64 output of the R50 root.)
 template <int CI, int R, int STRIDE, int PAD>
 __global__ __launch_bounds__(256) void root_fwd_kernel(const half_t* __restrict__ x, int ldx, const half_t* __restrict__ wp,
                                                        half_t* __restrict__ y, int ldy, int N, int H, int W, int Ho, int Wo,
                                                        int Co) {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];      // [R*R*CI][Co]
+    extern __shared__ __attribute__((aligned(16))) float wsm[];      // [R*R*CI][Co] fp32, then xs [R][Wp][CI] fp16
+    const int Wp = W + 2 * PAD + STRIDE;                              // padded row (+ slack for the pixels past Wo of the last lane)
+    half_t* xs = reinterpret_cast<half_t*>(wsm + R * R * CI * Co);
     const int tid = threadIdx.x;
     const int G = Co >> 3, PL = 256 / G;
     const int cg = tid % G, pl = tid / G;
     for (int i = tid; i < R * R * CI * Co; i += 256) wsm[i] = (float)wp[i];
-    __syncthreads();
-    const long P = (long)N * Ho * Wo;
-    const long p0 = (long)blockIdx.x * ROOT_PPB;
-    for (long p = p0 + pl; p < p0 + ROOT_PPB && p < P; p += PL) {
-        const int n = (int)(p / ((long)Ho * Wo));
-        const int r = (int)(p - (long)n * Ho * Wo);
-        const int ho = r / Wo, wo = r - ho * Wo;
-        float acc[8];
+    const int rows_per_img = (Ho + ROOT_ROWS - 1) / ROOT_ROWS;
+    const int n = blockIdx.x / rows_per_img, ho0 = (blockIdx.x % rows_per_img) * ROOT_ROWS;
+    for (int ho = ho0; ho < ho0 + ROOT_ROWS && ho < Ho; ++ho) {
+        __syncthreads();                                              // (weights staged / previous row's readers done)
+        for (int i = tid; i < R * Wp * CI; i += 256) {
+            const int ci = i % CI, col = (i / CI) % Wp, ty = i / (CI * Wp);
+            const int hi = ho * STRIDE + ty - PAD, wi = col - PAD;
+            xs[i] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((long)((long)n * H + hi) * W + wi) * ldx + ci] : (half_t)0.f;
+        }
+        __syncthreads();
+        for (int w0 = 0; w0 < Wo; w0 += 4 * PL) {
+            float acc[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        for (int ty = 0; ty < R; ++ty) {
-            const int hi = ho * STRIDE + ty - PAD;
-            if (hi < 0 || hi >= H) continue;
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int tx_ = 0; tx_ < R; ++tx_) {
-                const int wi = wo * STRIDE + tx_ - PAD;
-                if (wi < 0 || wi >= W) continue;
-                const half_t* xp = x + ((long)((long)n * H + hi) * W + wi) * ldx;
+                for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
+            int col[4];
 #pragma unroll
-                for (int ci = 0; ci < CI; ++ci) {
-                    const float v = (float)xp[ci];
-                    const float4* wrow = reinterpret_cast<const float4*>(wsm + ((ty * R + tx_) * CI + ci) * Co + cg * 8);
-                    const float4 w0 = wrow[0], w1 = wrow[1];
-                    acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]);
-                    acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
-                    acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]);
-                    acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int wo = w0 + pl + u * PL;
+                col[u] = (wo < Wo ? wo : 0) * STRIDE;                 // (lanes past the row compute pixel 0 and do not store)
+            }
+            for (int ty = 0; ty < R; ++ty)
+#pragma unroll
+                for (int tx_ = 0; tx_ < R; ++tx_)
+#pragma unroll
+                    for (int ci = 0; ci < CI; ++ci) {
+                        const float4* wrow = reinterpret_cast<const float4*>(wsm + ((ty * R + tx_) * CI + ci) * Co + cg * 8);
+                        const float4 w0v = wrow[0], w1v = wrow[1];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float v = (float)xs[(ty * Wp + col[u] + tx_) * CI + ci];
+                            acc[u][0] = fmaf(v, w0v.x, acc[u][0]); acc[u][1] = fmaf(v, w0v.y, acc[u][1]);
+                            acc[u][2] = fmaf(v, w0v.z, acc[u][2]); acc[u][3] = fmaf(v, w0v.w, acc[u][3]);
+                            acc[u][4] = fmaf(v, w1v.x, acc[u][4]); acc[u][5] = fmaf(v, w1v.y, acc[u][5]);
+                            acc[u][6] = fmaf(v, w1v.z, acc[u][6]); acc[u][7] = fmaf(v, w1v.w, acc[u][7]);
+                        }
+                    }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int wo = w0 + pl + u * PL;
+                if (wo >= Wo) continue;
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[u][j];
+                *reinterpret_cast<half8*>(y + ((long)((long)n * Ho + ho) * Wo + wo) * ldy + cg * 8) = o;
             }
         }
-        half8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
-        *reinterpret_cast<half8*>(y + p * ldy + cg * 8) = o;
     }
 }
 
-// root weight gradient partials, one tap row per blockIdx.y: part[((blk*R*R + tap)*CI + ci)*Co + co]
+// root weight gradient partials, one tap row (ty) per blockIdx.y, ROOT_WROWS output rows of one image per blockIdx.x:
+// part[((blk*R*R + ty*R + tx)*CI + ci)*Co + co].  The one input row a (output row, ty) pair reads is staged in LDS
+// (zero-padded), the gradient rows of 4 pixels per thread are loaded up front: the first version took both from global memory
+// pixel by pixel, one round trip each (446 us on the R50 root).
 template <int CI, int R, int STRIDE, int PAD>
 __global__ __launch_bounds__(256) void root_wgrad_kernel(const half_t* __restrict__ x, int ldx, const half_t* __restrict__ dy,
                                                          int lddy, float* __restrict__ part, int N, int H, int W, int Ho,
                                                          int Wo, int Co) {
-    __shared__ float red[256][9];
+    extern __shared__ __attribute__((aligned(16))) float red_[];     // red [256][9] floats, then xs [Wp][CI] fp16
+    float (*red)[9] = reinterpret_cast<float (*)[9]>(red_);
+    half_t* xs = reinterpret_cast<half_t*>(red_ + 256 * 9);
+    const int Wp = W + 2 * PAD + STRIDE;
     const int tid = threadIdx.x, ty = blockIdx.y;
     const int G = Co >> 3, PL = 256 / G;
     const int cg = tid % G, pl = tid / G;
-    const long P = (long)N * Ho * Wo;
-    const long p0 = (long)blockIdx.x * WG_PPB;
+    const int rows_per_img = (Ho + ROOT_WROWS - 1) / ROOT_WROWS;
+    const int n = blockIdx.x / rows_per_img, ho0 = (blockIdx.x % rows_per_img) * ROOT_WROWS;
     float acc[R][CI][8];
 #pragma unroll
     for (int t = 0; t < R; ++t)
@@ -88,26 +116,39 @@ __global__ __launch_bounds__(256) void root_wgrad_kernel(const half_t* __restric
         for (int c = 0; c < CI; ++c)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[t][c][j] = 0.f;
-    for (long p = p0 + pl; p < p0 + WG_PPB && p < P; p += PL) {
-        const int n = (int)(p / ((long)Ho * Wo));
-        const int r = (int)(p - (long)n * Ho * Wo);
-        const int ho = r / Wo, wo = r - ho * Wo;
+    for (int ho = ho0; ho < ho0 + ROOT_WROWS && ho < Ho; ++ho) {
         const int hi = ho * STRIDE + ty - PAD;
-        if (hi < 0 || hi >= H) continue;
-        const half8 g = *reinterpret_cast<const half8*>(dy + p * lddy + cg * 8);
-        float gf[8];
+        if (hi < 0 || hi >= H) continue;                              // (uniform over the workgroup)
+        __syncthreads();
+        for (int i = tid; i < Wp * CI; i += 256) {
+            const int ci = i % CI, wi = i / CI - PAD;
+            xs[i] = (wi >= 0 && wi < W) ? x[((long)((long)n * H + hi) * W + wi) * ldx + ci] : (half_t)0.f;
+        }
+        __syncthreads();
+        for (int w0 = 0; w0 < Wo; w0 += 4 * PL) {
+            half8 g[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gf[j] = (float)g[j];
-        const half_t* xrow = x + ((long)n * H + hi) * W * ldx;
+            for (int u = 0; u < 4; ++u) {
+                const int wo = w0 + pl + u * PL;
 #pragma unroll
-        for (int tx_ = 0; tx_ < R; ++tx_) {
-            const int wi = wo * STRIDE + tx_ - PAD;
-            const bool in = wi >= 0 && wi < W;
+                for (int j = 0; j < 8; ++j) g[u][j] = (half_t)0.f;
+                if (wo < Wo) g[u] = *reinterpret_cast<const half8*>(dy + ((long)((long)n * Ho + ho) * Wo + wo) * lddy + cg * 8);
+            }
 #pragma unroll
-            for (int c = 0; c < CI; ++c) {
-                const float v = in ? (float)xrow[(long)wi * ldx + c] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int wo = w0 + pl + u * PL;
+                const int col = (wo < Wo ? wo : 0) * STRIDE;          // (past the row: zero gradient, any column)
+                float gf[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[tx_][c][j] = fmaf(v, gf[j], acc[tx_][c][j]);
+                for (int j = 0; j < 8; ++j) gf[j] = (float)g[u][j];
+#pragma unroll
+                for (int tx_ = 0; tx_ < R; ++tx_)
+#pragma unroll
+                    for (int c = 0; c < CI; ++c) {
+                        const float v = (float)xs[(col + tx_) * CI + c];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[tx_][c][j] = fmaf(v, gf[j], acc[tx_][c][j]);
+                    }
             }
         }
     }
@@ -242,9 +283,10 @@ bool umi_root_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldy,
 int umi_root_fwd(const void* x, int ldx, const void* wp, void* y, int ldy, int N, int H, int W, int Ho, int Wo, int Co,
                  hipStream_t s) {
     if (!al16(y)) return UMI_ERR_BADARG;
-    const long P = (long)N * Ho * Wo;
-    const int blocks = (int)((P + ROOT_PPB - 1) / ROOT_PPB);
-    hipLaunchKernelGGL((root_fwd_kernel<3, 7, 2, 3>), dim3(blocks), dim3(256), (size_t)49 * 3 * Co * 4, s, (const half_t*)x, ldx,
+    const int blocks = N * ((Ho + ROOT_ROWS - 1) / ROOT_ROWS);
+    const size_t smem = (size_t)49 * 3 * Co * 4 + (size_t)7 * (W + 8) * 3 * 2;
+    if (smem > 64 * 1024) return UMI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((root_fwd_kernel<3, 7, 2, 3>), dim3(blocks), dim3(256), smem, s, (const half_t*)x, ldx,
                        (const half_t*)wp, (half_t*)y, ldy, N, H, W, Ho, Wo, Co);
     UMI_LAUNCH_CHECK();
     return UMI_OK;
@@ -257,15 +299,16 @@ bool umi_root_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int ld
            Co <= 256 && lddy % 8 == 0;
 }
 size_t umi_root_wgrad_ws_bytes(int N, int Ho, int Wo, int Co) {
-    const long blocks = ((long)N * Ho * Wo + WG_PPB - 1) / WG_PPB;
+    const long blocks = (long)N * ((Ho + ROOT_WROWS - 1) / ROOT_WROWS);
     return (size_t)blocks * 49 * 3 * Co * sizeof(float);
 }
 int umi_root_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dW, long s_co, long s_ci, long s_t, float out_scale,
                    int N, int H, int W, int Ho, int Wo, int Co, void* ws, size_t ws_bytes, hipStream_t s) {
     if (ws_bytes < umi_root_wgrad_ws_bytes(N, Ho, Wo, Co)) return UMI_ERR_WORKSPACE;
     if (!al16(dy)) return UMI_ERR_BADARG;
-    const int blocks = (int)(((long)N * Ho * Wo + WG_PPB - 1) / WG_PPB);
-    hipLaunchKernelGGL((root_wgrad_kernel<3, 7, 2, 3>), dim3(blocks, 7), dim3(256), 0, s, (const half_t*)x, ldx,
+    const int blocks = N * ((Ho + ROOT_WROWS - 1) / ROOT_WROWS);
+    const size_t smem = (size_t)256 * 9 * 4 + (size_t)(W + 8) * 3 * 2;
+    hipLaunchKernelGGL((root_wgrad_kernel<3, 7, 2, 3>), dim3(blocks, 7), dim3(256), smem, s, (const half_t*)x, ldx,
                        (const half_t*)dy, lddy, (float*)ws, N, H, W, Ho, Wo, Co);
     UMI_LAUNCH_CHECK();
     umi_launch_wgrad_reduce((const float*)ws, blocks, 49, 3, Co, dW, s_co, s_ci, s_t, out_scale, s);

@@ -132,6 +132,8 @@ __global__ __launch_bounds__(256) void optim_multi_kernel(const OptDesc* __restr
     }
 }
 
+// (a variant with one thread per 8 outputs of the k8 layout -- coalesced reads for the data-gradient layouts -- measured
+// slower: 227 vs 173 us per launch on a TransUNet's 105 M parameters; the launch moves 1.26 GB, 0.31 ms at 4 TB/s)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restrict__ descs, int n_desc) {
     const int blk = blockIdx.x;
@@ -141,44 +143,33 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackDesc* __restr
     T* dst = (T*)d.dst;
     const int kb8 = d.Kpad >> 3;
     const int ldn = d.ldn ? d.ldn : d.Npad;
-    if (d.k8) {
-        // dst[t][k/8][n][k%8]: one thread = the 8 k of one (t, k/8, n), stored as one 16-B (fp16) / two 16-B (fp32) pieces.
-        // Consecutive threads walk n: where n is contiguous in the source (data-gradient layouts: sn == 1) every one of the
-        // 8 reads is coalesced across the wave, where k is (forward layouts: sk == 1) a thread reads 32 contiguous bytes.
-        // (One thread per OUTPUT element read the data-gradient sources 4 bytes per 64-byte line: 370 us per step for a
-        // TransUNet's 105 M parameters.)
-        const long item = base / 8 + threadIdx.x;                  // PACK_BLOCK / 8 == 256 items per workgroup
-        if (item * 8 >= total) return;
-        const int n = (int)(item % d.Npad);
-        const long r = item / d.Npad;
-        const int kb = (int)(r % kb8), t = (int)(r / kb8);
-        const int ts = d.flip_t ? (d.T - 1 - t) : t;
-        const float* src = d.src + ts * d.st + (long)n * d.sn;
-        T v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = kb * 8 + j;
-            v[j] = (T)((k < d.K && n < d.N) ? src[k * d.sk] : 0.f);
-        }
-        T* o = dst + (((long)t * kb8 + kb) * ldn + n) * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = v[j];                   // (adjacent, 16-B aligned: the compiler merges the stores)
-        return;
-    }
-    static_assert(PACK_BLOCK == 2048, "k8 items per workgroup == threads per workgroup");
 #pragma unroll 2
-    for (int j = 0; j < PACK_BLOCK / 256; ++j) {                   // dst[t][k][n]
+    for (int j = 0; j < PACK_BLOCK / 256; ++j) {
         const long i = base + j * 256 + threadIdx.x;
         if (i >= total) break;
-        const int n = (int)(i % d.Npad);
-        const long r = i / d.Npad;
-        const int k = (int)(r % d.Kpad), t = (int)(r / d.Kpad);
+        int n, k, t;
+        long o;                          // destination index (== i unless the entry is a column slice: ldn > Npad)
+        if (d.k8) {                      // dst[t][k/8][n][k%8]
+            const int k8 = (int)(i & 7);
+            long r = i >> 3;
+            n = (int)(r % d.Npad); r /= d.Npad;
+            const int kb = (int)(r % kb8);
+            t = (int)(r / kb8);
+            k = kb * 8 + k8;
+            o = (((long)t * kb8 + kb) * ldn + n) * 8 + k8;
+        } else {                         // dst[t][k][n]
+            n = (int)(i % d.Npad);
+            const long r = i / d.Npad;
+            k = (int)(r % d.Kpad);
+            t = (int)(r / d.Kpad);
+            o = ((long)t * d.Kpad + k) * ldn + n;
+        }
         float v = 0.f;
         if (k < d.K && n < d.N) {
             const int ts = d.flip_t ? (d.T - 1 - t) : t;
             v = d.src[ts * d.st + k * d.sk + n * d.sn];
         }
-        dst[((long)t * d.Kpad + k) * ldn + n] = (T)v;
+        dst[o] = (T)v;
     }
 }
 
