@@ -258,6 +258,12 @@ int umi_elementwise(int mode, const void* x, int ldx, const void* g, int ldg, vo
  * from a captured HIP graph still draws a fresh mask every replay. */
 int umi_dropout(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
                 int dtype, const void* tx, const unsigned* seed_dev, umi_stream_t stream);
+/* umi_dropout fused with the GELU before it and / or the residual add after it (the MLP and the two residual joins of a
+ * transformer Block, reference vit_seg_modeling.py:113-119,177-187); fp16 with C % 8 == 0 only (UMI_ERR_UNSUPPORTED otherwise):
+ *   forward : y = dropout(gelu ? GELU(x) : x) + (aux ? aux : 0)
+ *   backward: y = dropout'(x) * (gelu ? GELU'(aux) : 1), aux = the forward's x.  Same mask bytes / random stream as umi_dropout. */
+int umi_dropout_fused(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
+                      int dtype, const unsigned* seed_dev, const void* aux, int ldaux, int gelu, umi_stream_t stream);
 
 /* Multi-head softmax attention (vit_seg_modeling.py:73-91): q,k,v,o are [B, N, heads*D] token tensors (row stride ld),
  * head h = channels [h*D, (h+1)*D); softmax(q k^T / sqrt(D)) v.  lse/delta: [B*heads*N] fp32 scratch kept for backward. */

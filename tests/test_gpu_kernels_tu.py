@@ -586,3 +586,35 @@ def test_group_norm_per_channel_groups_and_deferred_param_grads():
     _close(db2, db, 1e-6)
     _close(db, br.grad * 0.5, 2e-3)
     _close(dg, gr.grad * 0.5, 2e-2)
+
+
+@pytest.mark.parametrize("gelu,with_add", [(True, False), (False, True), (True, True)])
+def test_fused_dropout_matches_the_separate_kernels(gelu, with_add):
+    """umi_dropout_fused (GELU -> dropout -> + residual in one kernel, and its backward) against GELU, dropout and add run one
+    after the other with the same seed: the same mask bytes, values equal up to the roundings the fusion removes."""
+    lib, ops, T = _gpu()
+    M, C, p, seed = 300, 768, 0.1, 12345
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 1, M, C, generator=g).half().to(DEV)
+    h = torch.randn(1, 1, M, C, generator=g).half().to(DEV)
+    dy = torch.randn(1, 1, M, C, generator=g).half().to(DEV)
+    y, mask = torch.empty_like(x), torch.empty(M * C, dtype=torch.uint8, device=DEV)
+    assert T.dropout_fused(x, y, mask, False, p, seed, None, h if with_add else None, gelu)
+    a = x
+    if gelu:
+        a = torch.empty_like(x)
+        T.gelu_fwd(x, a)
+    y_ref, mask_ref = torch.empty_like(x), torch.empty_like(mask)
+    T.dropout(a, y_ref, mask_ref, False, p, seed)
+    if with_add:
+        T.add(y_ref, h, y_ref)
+    assert torch.equal(mask, mask_ref)
+    assert 0.85 < mask.float().mean().item() < 0.95
+    _close(y, y_ref, 2e-3)
+    dx, dx_ref = torch.empty_like(x), torch.empty_like(x)
+    if gelu:
+        assert T.dropout_fused(dy, dx, mask, True, p, 0, None, x, True)
+        tmp = torch.empty_like(x)
+        T.dropout(dy, tmp, mask, True, p, 0)
+        T.gelu_bwd(x, tmp, dx_ref)
+        _close(dx, dx_ref, 2e-3)

@@ -266,24 +266,24 @@ class DecoderCup(nn.Module):
 
 
 # ---- tape builders -------------------------------------------------------------------------------------------------------
-def _build_attention(t, x, attn: Attention):
+def _build_attention(t, x, attn: Attention, residual=None):
+    """`residual`: the block's skip input, added by the projection dropout's kernel (Block.forward's `x + h`)."""
     if attn.attn_dropout.p > 0 and t.training:
         raise NotImplementedError("attention-probability dropout > 0 is not supported (all reference configs use 0.0)")
     ctx = t.qkv_attention(x, attn.query, attn.key, attn.value, attn.num_attention_heads)
-    return t.dropout(t.linear(ctx, attn.out.weight, attn.out.bias), attn.proj_dropout.p)
+    return t.dropout(t.linear(ctx, attn.out.weight, attn.out.bias), attn.proj_dropout.p, add=residual)
 
 
-def _build_mlp(t, x, mlp: Mlp):
-    x = t.dropout(t.gelu(t.linear(x, mlp.fc1.weight, mlp.fc1.bias)), mlp.dropout.p)
-    return t.dropout(t.linear(x, mlp.fc2.weight, mlp.fc2.bias), mlp.dropout.p)
+def _build_mlp(t, x, mlp: Mlp, residual=None):
+    """`residual`: the block's skip input, added by the last dropout's kernel (Block.forward's `x + h`)."""
+    x = t.dropout(t.linear(x, mlp.fc1.weight, mlp.fc1.bias), mlp.dropout.p, gelu=True)
+    return t.dropout(t.linear(x, mlp.fc2.weight, mlp.fc2.bias), mlp.dropout.p, add=residual)
 
 
 def _build_block(t, h, blk: Block, cfg=None):
     """Pre-LN block (reference :177-187).  Rates and head count come from the modules themselves (== cfg.transformer[...])."""
-    a = _build_attention(t, t.layer_norm(h, blk.attention_norm), blk.attn)
-    h = t.add(a, h)
-    x = _build_mlp(t, t.layer_norm(h, blk.ffn_norm), blk.ffn)
-    return t.add(x, h)
+    h = _build_attention(t, t.layer_norm(h, blk.attention_norm), blk.attn, residual=h)
+    return _build_mlp(t, t.layer_norm(h, blk.ffn_norm), blk.ffn, residual=h)
 
 
 def _build_embeddings(t, a, emb: Embeddings):

@@ -87,6 +87,53 @@ __global__ __launch_bounds__(256) void dropout8_kernel(const half_t* __restrict_
     }
 }
 
+// Dropout fused with its neighbours in a transformer block (vit_seg_modeling.py:113-119,177-187):
+//   forward : y = dropout(GELU ? gelu(x) : x) + (AUX ? aux : 0)       (MLP: fc1 -> GELU -> dropout;  residual: dropout(f(x)) + h)
+//   backward: y = dropout'(x) * (GELU ? gelu'(aux) : 1)                (aux = the forward's pre-activation)
+// Same random stream (element index, seed) and mask bytes as dropout8_kernel; one rounding to fp16 instead of two or three.
+template <bool GELU, bool AUX>
+__global__ __launch_bounds__(256) void dropout8_fused_kernel(const half_t* __restrict__ x, int ldx, half_t* __restrict__ y, int ldy,
+                                                             unsigned char* __restrict__ mask, int bwd, float p, unsigned seed,
+                                                             long M, int C8, const unsigned* __restrict__ seed_dev,
+                                                             const half_t* __restrict__ aux, int ldaux) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B9u;
+    const long total = M * C8;
+    const float scale = 1.f / (1.f - p);
+    const int C = C8 * 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long r = i / C8;
+        const long e0 = r * C + c;
+        half8 xv = *reinterpret_cast<const half8*>(x + r * ldx + c), av, o;
+        if (AUX || (GELU && bwd)) av = *reinterpret_cast<const half8*>(aux + r * ldaux + c);
+        unsigned long long mk = 0;
+        if (bwd) mk = *reinterpret_cast<const unsigned long long*>(mask + e0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned k;
+            if (bwd) k = (unsigned)(mk >> (8 * j)) & 0xFFu;
+            else {
+                const long e = e0 + j;
+                float u = (hash32((unsigned)e, seed ^ (unsigned)(e >> 32)) >> 8) * (1.f / 16777216.f);
+                k = u >= p;
+                mk |= (unsigned long long)k << (8 * j);
+            }
+            float v = (float)xv[j];
+            if (!bwd) {
+                if (GELU) v = gelu_f(v);
+                v = k ? v * scale : 0.f;
+                if (AUX) v += (float)av[j];
+            } else {
+                v = k ? v * scale : 0.f;
+                if (GELU) v *= gelu_df((float)av[j]);
+            }
+            o[j] = (half_t)v;
+        }
+        if (!bwd) *reinterpret_cast<unsigned long long*>(mask + e0) = mk;
+        *reinterpret_cast<half8*>(y + r * ldy + c) = o;
+    }
+}
+
 // LayerNorm backward: one wave per row, lane owns K4 groups of 4 channels (C <= 4*64*K4; C = 768 -> K4 = 3); dgamma/dbeta
 // stay in registers across the rows of a wave and leave as one partial row per workgroup (fixed order => deterministic)
 constexpr int LNV_ROWS = 16;       // rows per backward workgroup (4 per wave)
@@ -264,6 +311,22 @@ bool umi_dropout_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int 
     const int C8 = C / 8;
     hipLaunchKernelGGL(dropout8_kernel, dim3(grid8(M * C8)), dim3(256), 0, s, (const half_t*)x, ldx, (half_t*)y, ldy,
                        (unsigned char*)mask, backward, p, seed, M, C8, (const float4*)tx, seed_dev);
+    return true;
+}
+
+bool umi_dropout_fused_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M,
+                            int C, const unsigned* seed_dev, const void* aux, int ldaux, int gelu, hipStream_t s) {
+    const bool need_aux = backward ? gelu != 0 : aux != nullptr;
+    if (C % 8 || ldx % 8 || ldy % 8 || !al16(x) || !al16(y) || (((uintptr_t)mask) & 7) || (need_aux && (!aux || ldaux % 8 || !al16(aux))))
+        return false;
+    const int C8 = C / 8;
+    const dim3 grid(grid8(M * C8));
+#define GO(G_, A_)                                                                                                    \
+    hipLaunchKernelGGL((dropout8_fused_kernel<G_, A_>), grid, dim3(256), 0, s, (const half_t*)x, ldx, (half_t*)y, ldy,  \
+                       (unsigned char*)mask, backward, p, seed, M, C8, seed_dev, (const half_t*)aux, ldaux)
+    if (gelu) { if (!backward && aux) GO(true, true); else GO(true, false); }
+    else { if (!backward && aux) GO(false, true); else GO(false, false); }
+#undef GO
     return true;
 }
 

@@ -613,6 +613,8 @@ bool umi_pool3s2_fwd_f16v(const void* x, int ldx, void* y, int ldy, void* idx, i
 bool umi_pool3s2_bwd_f16v(const void* dy, int lddy, const void* idx, void* dx, int lddx, int N, int H, int W, int C, hipStream_t s);
 bool umi_dropout_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M, int C,
                       const void* tx, const unsigned* seed_dev, hipStream_t s);
+bool umi_dropout_fused_f16v(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M,
+                            int C, const unsigned* seed_dev, const void* aux, int ldaux, int gelu, hipStream_t s);
 int umi_ln_bwd_rows_f16v();
 bool umi_ln_bwd_f16v(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
                      void* dx, int lddx, float* part, long M, int C, hipStream_t s);
@@ -811,6 +813,20 @@ extern "C" int umi_elementwise(int mode, const void* x, int ldx, const void* g, 
     DT_SWITCH(dtype,
         hipLaunchKernelGGL(ew_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)st, mode, (const float*)x, ldx, (const float*)g, ldg, (float*)y, ldy, M, C, bcast_rows > 0 ? bcast_rows : 1),
         hipLaunchKernelGGL(ew_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)st, mode, (const half_t*)x, ldx, (const half_t*)g, ldg, (half_t*)y, ldy, M, C, bcast_rows > 0 ? bcast_rows : 1))
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+// umi_dropout fused with the GELU before it and / or the residual add after it (fp16, C % 8 == 0: UMI_ERR_UNSUPPORTED
+// otherwise, run the separate kernels):  forward  y = dropout(gelu ? GELU(x) : x) + (aux ? aux : 0)
+//                                         backward y = dropout'(x) * (gelu ? GELU'(aux) : 1), aux = the forward's x
+extern "C" int umi_dropout_fused(const void* x, int ldx, void* y, int ldy, void* mask, int backward, float p, unsigned seed, long M,
+                                 int C, int dtype, const unsigned* seed_dev, const void* aux, int ldaux, int gelu,
+                                 umi_stream_t st) {
+    if (!x || !y || !mask || M <= 0 || C <= 0 || p < 0.f || p >= 1.f) return UMI_ERR_BADARG;
+    if (dtype != UMI_F16 ||
+        !umi_dropout_fused_f16v(x, ldx, y, ldy, mask, backward, p, seed, M, C, seed_dev, aux, ldaux, gelu, (hipStream_t)st))
+        return UMI_ERR_UNSUPPORTED;
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }

@@ -340,20 +340,37 @@ class TUTape(Tape):
             self.steps.append(bwd)
         return o
 
-    def dropout(self, a: Act, p):
+    def dropout(self, a: Act, p, gelu=False, add: Act = None):
+        """Dropout(p), optionally with the GELU before it and / or a residual add after it in the same kernel:
+        dropout(gelu(a)) + add  (reference Mlp.forward vit_seg_modeling.py:113-119, Block.forward :177-187)."""
         if not self.training or p <= 0.0:
-            return a
+            o = self.gelu(a) if gelu else a
+            return self.add(o, add) if add is not None else o
         out = torch.empty_like(a.raw)
         mask = torch.empty(a.raw.numel(), dtype=torch.uint8, device=a.raw.device)
         self._drop_count += 1
-        ops_tu.dropout(a.raw, out, mask, False, p, self._seed * 7919 + self._drop_count, seed_dev=self._seed_dev)
+        seed = self._seed * 7919 + self._drop_count
+        if gelu or add is not None:
+            if not (a.tx is None and (add is None or add.tx is None) and
+                    ops_tu.dropout_fused(a.raw, out, mask, False, p, seed, self._seed_dev, add.raw if add is not None else None, gelu)):
+                self._drop_count -= 1                  # unfused: the same ops one after the other
+                o = self.dropout(self.gelu(a) if gelu else a, p)
+                return self.add(o, add) if add is not None else o
+        else:
+            ops_tu.dropout(a.raw, out, mask, False, p, seed, seed_dev=self._seed_dev)
         o = Act(out, None)
         if self.record:
             def bwd():
                 if o.grad is None:
                     return
                 dx = torch.empty_like(a.raw)
-                ops_tu.dropout(o.grad, dx, mask, True, p, 0)
+                if gelu:
+                    assert ops_tu.dropout_fused(o.grad, dx, mask, True, p, 0, None, a.raw, True)
+                else:
+                    ops_tu.dropout(o.grad, dx, mask, True, p, 0)
+                if add is not None:                    # the residual branch receives the same tensor (read-only, see add())
+                    self._readonly.add(o.grad.data_ptr())
+                    self._give(add, o.grad)
                 self._give(a, dx)
             self.steps.append(bwd)
         return o

@@ -94,6 +94,8 @@ SIGNATURES = {
     "umi_elementwise": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_long, c_int, c_void_p]),
     "umi_dropout": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_float, ctypes.c_uint, c_long, c_int, c_int,
                             c_void_p, c_void_p, c_void_p]),
+    "umi_dropout_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_float, ctypes.c_uint, c_long, c_int, c_int,
+                                  c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "umi_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_void_p]),
     "umi_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -135,6 +135,19 @@ def dropout(x, y, mask, backward, p, seed, tx=None, seed_dev=None):
                                 seed & 0xFFFFFFFF, M, C, _dt(x), _ptr(tx), _ptr(seed_dev), _stream()), "umi_dropout")
 
 
+def dropout_fused(x, y, mask, backward, p, seed, seed_dev=None, aux=None, gelu=False):
+    """Forward y = dropout(gelu(x) if gelu else x) + (aux or 0); backward y = dropout'(x) * (gelu'(aux) if gelu else 1).
+    False where the fused kernel does not apply (nothing was launched)."""
+    M, C, ldx = _rows(x)
+    st = L.fn("umi_dropout_fused")(x.data_ptr(), ldx, y.data_ptr(), _rows(y)[2], mask.data_ptr(), int(backward), p,
+                                   seed & 0xFFFFFFFF, M, C, _dt(x), _ptr(seed_dev), _ptr(aux),
+                                   _rows(aux)[2] if aux is not None else 0, int(gelu), _stream())
+    if st == -2:
+        return False
+    L.check(st, "umi_dropout_fused")
+    return True
+
+
 def attn_fwd(q, k, v, o, heads):
     B, _, N, C = q.shape
     D = C // heads
