@@ -239,13 +239,14 @@ int umi_pool3s2_fwd(const void* x, int ldx, void* y, int ldy, void* idx, int N, 
 int umi_pool3s2_bwd(const void* dy, int lddy, const void* x, int ldx, const void* idx, void* dx, int lddx, int N, int H, int W,
                     int C, int dtype, umi_stream_t stream);
 
-/* LayerNorm over the last dim (vit_seg_modeling.py:172-173,232; eps 1e-6) and backward. */
+/* LayerNorm over the last dim (vit_seg_modeling.py:172-173,232; eps 1e-6) and backward.  * umi_ln_bwd with dgamma == dbeta == NULL leaves its partial rows [*rows_out][2][C] in `ws` (then a buffer of the caller's
+ * that stays alive) for umi_gn_param_grads_group (N = *rows_out) to sum for many layers in one launch. */
 int umi_ln_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean, float* rstd,
                long M, int C, float eps, int dtype, umi_stream_t stream);
 size_t umi_ln_bwd_ws_bytes(long M, int C);
-int umi_ln_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
-               void* dx, int lddx, float* dgamma, float* dbeta, float out_scale, long M, int C, int dtype,
-               void* ws, size_t ws_bytes, umi_stream_t stream);
+int umi_ln_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean,
+               const float* rstd, void* dx, int lddx, float* dgamma, float* dbeta, float out_scale, long M, int C,
+               int dtype, void* ws, size_t ws_bytes, int* rows_out, umi_stream_t stream);
 
 /* Elementwise: mode 0 y = gelu(x) (exact erf form, vit_seg_modeling.py:115); 1 y = g * gelu'(x); 2 y = x + g;
  * 3 y = x + g[row % bcast_rows] (position embedding, vit_seg_modeling.py:163). */

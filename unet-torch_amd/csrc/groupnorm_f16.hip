@@ -269,18 +269,25 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_fin_kernel(const half_t* __r
 #undef UMI_GN_BAPPLY
 }
 
-// dgamma / dbeta of up to 16 GroupNorm layers per launch: out[c] = scale * sum over the N samples of part[n][which][c]
-// (fp64, fixed order).  blockIdx.y = layer, thread = channel.
+// dgamma / dbeta of up to 16 normalisation layers per launch: out[c] = scale * sum over the N rows of part[n][which][c]
+// (fp64; rows split over 4 lanes in a fixed pattern).  GroupNorm: N = samples; LayerNorm: N = its kernel's partial rows.
+// blockIdx.y = layer, 64 channels x 4 row lanes per workgroup.
 struct GnPg { const float* part[16]; float* dgamma[16]; float* dbeta[16]; int C[16]; };
 __global__ __launch_bounds__(256) void gn_param_grads_kernel(GnPg t, int N, float scale) {
+    __shared__ double sh[4][64];
     const int l = blockIdx.y, C = t.C[l];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
-    const int which = i / C, c = i - which * C;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;                      // index into the 2*C outputs (which = i / C)
+    const int which = i < 2 * C ? i / C : 0, c = i < 2 * C ? i - which * C : 0;
     double a = 0.0;
-#pragma unroll 8
-    for (int n = 0; n < N; ++n) a += (double)t.part[l][((long)n * 2 + which) * C + c];
-    (which ? t.dbeta[l] : t.dgamma[l])[c] = (float)(a * (double)scale);
+    if (i < 2 * C) {
+#pragma unroll 4
+        for (int n = rl; n < N; n += 4) a += (double)t.part[l][((long)n * 2 + which) * C + c];
+    }
+    sh[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && i < 2 * C)
+        (which ? t.dbeta[l] : t.dgamma[l])[c] = (float)((sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]) * (double)scale);
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -334,6 +341,6 @@ void umi_gn_param_grads_launch(int n, const float* const* parts, const int* Cs, 
             t.part[i] = parts[j]; t.dgamma[i] = dgammas[j]; t.dbeta[i] = dbetas[j]; t.C[i] = Cs[j];
             if (Cs[j] > maxC) maxC = Cs[j];
         }
-        hipLaunchKernelGGL(gn_param_grads_kernel, dim3((2 * maxC + 255) / 256, cnt), dim3(256), 0, s, t, N, scale);
+        hipLaunchKernelGGL(gn_param_grads_kernel, dim3((2 * maxC + 63) / 64, cnt), dim3(256), 0, s, t, N, scale);
     }
 }

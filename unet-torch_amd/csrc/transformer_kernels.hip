@@ -779,15 +779,20 @@ extern "C" size_t umi_ln_bwd_ws_bytes(long M, int C) {
 }
 extern "C" int umi_ln_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean,
                           const float* rstd, void* dx, int lddx, float* dgamma, float* dbeta, float out_scale, long M, int C,
-                          int dtype, void* ws, size_t ws_bytes, umi_stream_t st) {
-    if (!dy || !x || !dx || !dgamma || !dbeta || !ws) return UMI_ERR_BADARG;
+                          int dtype, void* ws, size_t ws_bytes, int* rows_out, umi_stream_t st) {
+    // dgamma == dbeta == NULL: the partial rows [rows][2][C] stay in `ws` (the caller's own buffer then, not scratch) for a
+    // later umi_gn_param_grads_group over many layers; *rows_out = their count
+    if (!dy || !x || !dx || !ws || (!dgamma != !dbeta) || (!dgamma && !rows_out)) return UMI_ERR_BADARG;
     if (ws_bytes < umi_ln_bwd_ws_bytes(M, C)) return UMI_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)st;
     if (dtype == UMI_F16 && umi_ln_bwd_f16v(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (float*)ws, M, C, s)) {
         UMI_LAUNCH_CHECK();
         const int vrows = (int)((M + umi_ln_bwd_rows_f16v() - 1) / umi_ln_bwd_rows_f16v());
-        umi_launch_reduce_rows2((const float*)ws, vrows, C, dgamma, dbeta, out_scale, s);
-        UMI_LAUNCH_CHECK();
+        if (rows_out) *rows_out = vrows;
+        if (dgamma) {
+            umi_launch_reduce_rows2((const float*)ws, vrows, C, dgamma, dbeta, out_scale, s);
+            UMI_LAUNCH_CHECK();
+        }
         return UMI_OK;
     }
     if ((size_t)8 * C * sizeof(float) > 64 * 1024) return UMI_ERR_UNSUPPORTED;
@@ -797,8 +802,11 @@ extern "C" int umi_ln_bwd(const void* dy, int lddy, const void* x, int ldx, cons
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(rows), dim3(256), smem, s, (const float*)dy, lddy, (const float*)x, ldx, gamma, mean, rstd, (float*)dx, lddx, (float*)ws, M, C),
         hipLaunchKernelGGL(ln_bwd_kernel<half_t>, dim3(rows), dim3(256), smem, s, (const half_t*)dy, lddy, (const half_t*)x, ldx, gamma, mean, rstd, (half_t*)dx, lddx, (float*)ws, M, C))
     UMI_LAUNCH_CHECK();
-    umi_launch_reduce_rows2((const float*)ws, rows, C, dgamma, dbeta, out_scale, s);
-    UMI_LAUNCH_CHECK();
+    if (rows_out) *rows_out = rows;
+    if (dgamma) {
+        umi_launch_reduce_rows2((const float*)ws, rows, C, dgamma, dbeta, out_scale, s);
+        UMI_LAUNCH_CHECK();
+    }
     return UMI_OK;
 }
 

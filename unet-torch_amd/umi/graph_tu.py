@@ -285,7 +285,14 @@ class TUTape(Tape):
                 if o.grad is None:
                     return
                 dx = self.alloc(N, H, W, C, device=out.device)
-                dg, db = ops_tu.ln_bwd(o.grad, a.raw, g32, mean, rstd, dx, self.inv)
+                if (self.grad_sink is None and self.dtype == torch.float16 and id(ln.weight) not in self.param_grads
+                        and id(ln.bias) not in self.param_grads):
+                    part, rows = ops_tu.ln_bwd(o.grad, a.raw, g32, mean, rstd, dx, self.inv, keep_part=True)
+                    dg, db = torch.empty(C, dtype=torch.float32, device=out.device), torch.empty(C, dtype=torch.float32,
+                                                                                                  device=out.device)
+                    self._gn_pending.append((part, rows, dg, db))        # summed with the GroupNorm rows at the end of the pass
+                else:
+                    dg, db = ops_tu.ln_bwd(o.grad, a.raw, g32, mean, rstd, dx, self.inv)
                 self._set_pgrad(ln.weight, dg)
                 self._set_pgrad(ln.bias, db)
                 self._give(a, dx)

@@ -90,7 +90,7 @@ SIGNATURES = {
                            c_int, c_void_p]),
     "umi_ln_bwd_ws_bytes": (c_size_t, [c_long, c_int]),
     "umi_ln_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                           c_float, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                           c_float, c_long, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "umi_elementwise": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_long, c_int, c_long, c_int, c_void_p]),
     "umi_dropout": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_float, ctypes.c_uint, c_long, c_int, c_int,
                             c_void_p, c_void_p, c_void_p]),

@@ -92,15 +92,21 @@ def ln_fwd(x, gamma, beta, eps, y):
     return mean, rstd
 
 
-def ln_bwd(dy, x, gamma, mean, rstd, dx, out_scale):
+def ln_bwd(dy, x, gamma, mean, rstd, dx, out_scale, keep_part=False):
+    """keep_part: dgamma / dbeta are NOT computed; returns (partial rows [rows][2][C], rows) for gn_param_grads_group."""
+    import ctypes
     M, C, ldx = _rows(x)
-    dg = torch.empty(C, dtype=torch.float32, device=x.device)
-    db = torch.empty_like(dg)
-    ws = workspace(L.fn("umi_ln_bwd_ws_bytes")(M, C), x.device)
+    nb = L.fn("umi_ln_bwd_ws_bytes")(M, C)
+    rows = ctypes.c_int(0)
+    if keep_part:
+        ws, dg, db = torch.empty(nb, dtype=torch.uint8, device=x.device), None, None
+    else:
+        ws, dg = workspace(nb, x.device), torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
     L.check(L.fn("umi_ln_bwd")(dy.data_ptr(), _rows(dy)[2], x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
-                               rstd.data_ptr(), dx.data_ptr(), _rows(dx)[2], dg.data_ptr(), db.data_ptr(), out_scale, M, C,
-                               _dt(x), ws.data_ptr(), ws.numel(), _stream()), "umi_ln_bwd")
-    return dg, db
+                               rstd.data_ptr(), dx.data_ptr(), _rows(dx)[2], _ptr(dg), _ptr(db), out_scale, M, C,
+                               _dt(x), ws.data_ptr(), ws.numel(), ctypes.addressof(rows), _stream()), "umi_ln_bwd")
+    return (ws.view(torch.float32), rows.value) if keep_part else (dg, db)
 
 
 def elementwise(mode, x, g, y, bcast_rows=0):
