@@ -42,11 +42,18 @@ struct Geo {                  // geometry of the (optionally strided) source / d
     int accum;                // UMI_CONV_ACCUMULATE: y += result (fp16 add of the stored and the new value)
 };
 
+// Workgroups per CU: the 128 x 64 tiles keep 32 accumulators and fit 128 VGPRs, so FOUR of their workgroups share a CU (4 x 33 KB
+// of LDS): the counters of the 4,704-token linears (tools/experiments/pmc_gemm.py) show waves parked at s_waitcnt / barriers
+// for half of their cycles with two resident workgroups, MFMA pipes 21 % and LDS 33 % busy -- a synchronisation-bound loop
+// that more resident workgroups hide, not a bandwidth-bound one.
+#ifndef UMI_C1_OCC128
+#define UMI_C1_OCC128 4
+#endif
 template <int P, int BN, bool GATHER, bool OUT_UPS, bool HAS_TX>
-__global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
+__global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) void conv1x1_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     const float* __restrict__ bias, half_t* __restrict__ y, int ldy, long M, int Kc /*channels per tap of the source*/,
-    int Nc /*channels per tap of the destination*/, int n_co, int ntaps, Geo geo) {
+    int Nc /*channels per tap of the destination*/, int n_co, int ntaps, Geo geo, long ntiles) {
     constexpr int WN = BN / 64, WM = 4 / WN, NT = P / (32 * WM);
     constexpr int XB = P * ROWB, WB = BN * ROWB;
     constexpr int ERS = BN * 2 + 16, EB = P * ERS;
@@ -60,8 +67,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_mfma_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
-    const int cb = blockIdx.x % n_co;
-    const long m0 = (long)(blockIdx.x / n_co) * P;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own L2.  Tiles are numbered so that each XCD
+    // gets one contiguous run of them -- with the output-channel tile running fastest, the n_co tiles that share a pixel-row tile
+    // (the same 256 or 128 rows of x) run on ONE XCD and x crosses the fabric once, not up to 8 times (counters of the
+    // 4,704 x 3,072 -> 768 linear before this: 248 MB of L2 misses for 34 MB of operands, 5.3 TB/s of fabric traffic
+    // at the kernel's 47 us -- that, not LDS or MFMA issue, was its bound).
+    const int per_xcd = (int)gridDim.x >> 3;                  // the grid is a multiple of 8
+    const long tile = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    const int cb = (int)(tile % n_co);
+    const long m0 = (tile / n_co) * P;
     const int c0 = cb * BN;
     const int sub = tid & 7;
 
@@ -321,10 +336,10 @@ int launch(bool s2d, bool ups, const void* x, int ldx, const void* tx, const voi
            int ldy, long M, int Kc, int Nc, int Ntot, int ntaps, Geo geo, hipStream_t s) {
     const int n_co = (Ntot + BN - 1) / BN;
     const long nblk = ((M + P - 1) / P) * n_co;
-    dim3 grid((unsigned)nblk), block(256);
+    dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(256);
 #define GO(S2D, UPS, HT)                                                                                          \
     hipLaunchKernelGGL((conv1x1_mfma_kernel<P, BN, S2D, UPS, HT>), grid, block, 0, s, (const half_t*)x, ldx,      \
-                       (const float4*)tx, (const half_t*)wp8, bias, (half_t*)y, ldy, M, Kc, Nc, n_co, ntaps, geo)
+                       (const float4*)tx, (const half_t*)wp8, bias, (half_t*)y, ldy, M, Kc, Nc, n_co, ntaps, geo, nblk)
     if (s2d) { if (tx) GO(true, false, true); else GO(true, false, false); }
     else if (ups) { if (tx) GO(false, true, true); else GO(false, true, false); }
     else { if (tx) GO(false, false, true); else GO(false, false, false); }
