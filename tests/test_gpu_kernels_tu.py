@@ -618,3 +618,46 @@ def test_fused_dropout_matches_the_separate_kernels(gelu, with_add):
         T.dropout(dy, tmp, mask, True, p, 0)
         T.gelu_bwd(x, tmp, dx_ref)
         _close(dx, dx_ref, 2e-3)
+
+
+def test_pack_cache_wstd_and_side_by_side_operands_match_the_single_launch_paths():
+    """PackCache.refresh brings the standardised StdConv2d weights (one umi_wstd_fwd_multi launch), their kernel layouts and the
+    side-by-side Q/K/V operands (umi_pack_desc.ldn) up to date after a parameter update: identical to umi_wstd_fwd per conv, to
+    packing a torch.cat of the three weights, and the grouped standardisation backward to umi_wstd_bwd per conv."""
+    lib, ops, T = _gpu()
+    g = torch.Generator().manual_seed(11)
+    convs = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in [(64, 3, 7, 7), (128, 64, 1, 1), (64, 64, 3, 3),
+                                                                                (256, 128, 1, 1)]]
+    qkv = [torch.nn.Parameter(torch.randn(96, 72, generator=g).to(DEV)) for _ in range(3)]
+    bias = [torch.nn.Parameter(torch.randn(96, generator=g).to(DEV)) for _ in range(3)]
+    c = ops.PackCache()
+
+    def check():
+        ents = [c.wstd(w, 1e-5) for w in convs]
+        for w, e in zip(convs, ents):
+            ws, rstd = T.wstd_fwd(w, 1e-5)
+            assert torch.equal(e.ws, ws) and torch.equal(e.rstd, rstd)
+            k8 = w.shape[1] % 8 == 0                    # (the 3-channel root conv runs on its own kernel, plain layout)
+            for kind in ("conv_fwd", "conv_dgrad", "conv_dgrad_strided"):
+                assert torch.equal(c.get(kind, e.ws, torch.float16, k8), ops.PACKERS[kind](ws, torch.float16, k8=k8))
+        wcat = torch.cat([w.detach() for w in qkv], 0).reshape(288, 72, 1, 1)
+        for kind in ("conv_fwd", "conv_dgrad"):
+            for k8 in (True, False):
+                assert torch.equal(c.get_cat(kind, qkv, torch.float16, k8), ops.PACKERS[kind](wcat, torch.float16, k8=k8)), (kind, k8)
+        assert torch.equal(c.get_cat("bias", bias, torch.float32, False), torch.cat([b.detach() for b in bias]))
+        return ents
+
+    check()                                             # first use: per-entry launches
+    with torch.no_grad():                               # an optimizer step: everything is stale
+        for p in convs + qkv + bias:
+            p.mul_(0.9).add_(0.01)
+    c.refresh()                                         # one wstd launch + one pack launch per storage dtype
+    stale = [e for e in c.ents.values() if e.ver != c._ver(e.w())]
+    assert not stale
+    ents = check()
+    gflat = torch.randn(c.wstd_total, generator=g).to(DEV)
+    dflat = torch.empty_like(gflat)
+    c.wstd_bwd(ents, gflat, dflat)
+    for w, e in zip(convs, ents):
+        gw = gflat[e.off:e.off + w.numel()].view(w.shape)
+        assert torch.equal(dflat[e.off:e.off + w.numel()].view(w.shape), T.wstd_bwd(e.ws, e.rstd, gw.contiguous()))
