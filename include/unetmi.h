@@ -159,6 +159,22 @@ int umi_conv_wgrad(const void* x, int ldx, const void* txa, const void* dy, int 
                    float* dW, long s_co, long s_ci, long s_t, float out_scale,
                    int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
                    int Ho, int Wo, int dtype, int flags, void* ws, size_t ws_bytes, umi_stream_t stream);
+/* umi_conv_wgrad with its final split-K reduction recorded instead of launched: a reduction is a ~8-us launch over a few
+ * hundred KB, a U-Net step has 22 and a TransUNet step 62; umi_wgrad_reduce_group runs 16 per launch (same arithmetic and
+ * order, identical results).  `ws` must be the call's own and stay untouched until then.  out->part == NULL: the path taken
+ * reduces inside its kernel, dW is already final. */
+typedef struct umi_wgrad_pending {
+    const float* part;
+    float* dW;
+    long s_co, s_ci, s_t;
+    float scale;
+    int splits, RS, Ci, Co;
+} umi_wgrad_pending;
+int umi_conv_wgrad_deferred(const void* x, int ldx, const void* txa, const void* dy, int lddy, const void* txb,
+                            float* dW, long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co,
+                            int R, int S, int stride, int pad, int Ho, int Wo, int dtype, int flags, void* ws, size_t ws_bytes,
+                            umi_wgrad_pending* out, umi_stream_t stream);
+int umi_wgrad_reduce_group(int n, const void* items /* umi_wgrad_pending[n], host */, umi_stream_t stream);
 /* umi_conv_wgrad (R = S = 1, no transforms) for `n` layers of one shape in one launch: the per-layer weight gradients of a
  * ViT encoder (reference vit_seg_modeling.py:58-62,100-101, twelve Blocks), whose pixel dimension (tokens) is too short to
  * fill the chip one layer at a time without a deep split-K.  x / dy / dW: HOST arrays of n device pointers.  No workspace,

@@ -303,6 +303,23 @@ extern "C" size_t umi_conv_wgrad_ws_bytes(int N, int Ho, int Wo, int Ci, int Co,
     return g;
 }
 
+// umi_conv_wgrad whose final split-K reduction is RECORDED in *out instead of launched (umi_wgrad_reduce_group runs many of
+// them at once).  `ws` must then stay untouched until that launch; out->part == NULL when the path taken had no separate
+// reduction (the gradient is already in dW).
+void umi_wgrad_defer_set(void* slot);
+extern "C" int umi_conv_wgrad_deferred(const void* x, int ldx, const void* txa, const void* dy, int lddy, const void* txb,
+                                       float* dW, long s_co, long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci,
+                                       int Co, int R, int S, int stride, int pad, int Ho, int Wo, int dtype, int flags, void* ws,
+                                       size_t ws_bytes, umi_wgrad_pending* out, umi_stream_t stream) {
+    if (!out) return UMI_ERR_BADARG;
+    out->part = nullptr;
+    umi_wgrad_defer_set(out);
+    const int st = umi_conv_wgrad(x, ldx, txa, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S, stride, pad, Ho,
+                                  Wo, dtype, flags, ws, ws_bytes, stream);
+    umi_wgrad_defer_set(nullptr);
+    return st;
+}
+
 // umi_conv_wgrad for `n` pointwise convs / nn.Linear layers of ONE shape (M rows, Ci -> Co, same row strides) in one launch:
 // dW[i][co*s_co + ci*s_ci] = out_scale * sum_p x[i][p][ci] * dy[i][p][co].  No workspace: each output tile is owned by one
 // workgroup (fixed summation order).  UMI_ERR_UNSUPPORTED where the pointwise matrix-core kernel does not apply.

@@ -823,8 +823,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_v4_kernel(const float* __res
     }
 }
 
+// Deferred form: umi_conv_wgrad_deferred arms a slot; the one reduction a weight-gradient path would launch is recorded there
+// instead, and umi_wgrad_reduce_group later runs the reductions of many layers in one launch per 16 (a split-K reduction of a
+// small weight is a ~8-us launch for a few hundred KB; a U-Net step has 22 of them, a TransUNet step 62).
+struct WgPending { const float* part; float* dW; long s_co, s_ci, s_t; float scale; int splits, RS, Ci, Co; };   // = umi_wgrad_pending
+static thread_local WgPending* g_wgrad_defer = nullptr;
+void umi_wgrad_defer_set(void* slot) { g_wgrad_defer = (WgPending*)slot; }
+
 void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
                              long s_t, float scale, hipStream_t st) {
+    if (g_wgrad_defer) {
+        *g_wgrad_defer = WgPending{part, dW, s_co, s_ci, s_t, scale, splits, RS, Ci, Co};
+        g_wgrad_defer = nullptr;
+        return;
+    }
     if (Co % 4 == 0 && (((uintptr_t)part) & 15) == 0) {
         long g4 = ((long)RS * Ci * Co / 4 + 31) / 32;
         if (g4 > 16384) g4 = 16384;
@@ -835,6 +847,90 @@ void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int 
     long g = (total + 31) / 32;
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
+}
+
+// up to 16 recorded reductions per launch: blockIdx.y = entry, the block loop and the arithmetic (lane l sums splits l, l+8, ...
+// in two chains, lanes added in order) are wgrad_reduce_v4_kernel's / wgrad_reduce_kernel's, so the results are identical
+struct WgTable { WgPending e[16]; int blk0[17]; };          // blk0: first workgroup of each entry (entry i owns blk0[i+1] - blk0[i])
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgTable t) {
+    __shared__ float4 red[8][33];
+    int ent = 0;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) ent += (int)blockIdx.x >= t.blk0[i];
+    const WgPending d = t.e[ent];
+    const int my_blk = (int)blockIdx.x - t.blk0[ent], n_blk = t.blk0[ent + 1] - t.blk0[ent];
+    const int ox = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const bool vec = d.Co % 4 == 0 && (((uintptr_t)d.part) & 15) == 0;
+    const int W4 = vec ? 4 : 1;
+    const long total = (long)d.RS * d.Ci * d.Co / W4;
+    const int CoW = d.Co / W4;
+    for (long base = (long)my_blk * 32; base < total; base += (long)n_blk * 32) {
+        const long i = base + ox;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (i < total) {
+            if (vec) {
+                const float4* p = reinterpret_cast<const float4*>(d.part) + i;
+                int z = sl;
+                for (; z + 8 < d.splits; z += 16) {
+                    float4 u = p[(long)z * total], v = p[(long)(z + 8) * total];
+                    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+                }
+                if (z < d.splits) { float4 u = p[(long)z * total]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+                a = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            } else {
+                for (int z = sl; z < d.splits; z += 8) a.x += d.part[(long)z * total + i];
+            }
+        }
+        red[sl][ox] = a;
+        __syncthreads();
+        if (sl == 0 && i < total) {
+            float4 t4 = red[0][ox];
+            if (vec) {
+#pragma unroll
+                for (int k = 1; k < 8; ++k) { float4 u = red[k][ox]; t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w; }
+            } else {
+                float s0 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s0 += red[k][ox].x;
+                t4.x = s0;
+            }
+            const int co = (int)(i % CoW) * W4;
+            const long rr = i / CoW;
+            const int ci = (int)(rr % d.Ci), tp = (int)(rr / d.Ci);
+            float* o = d.dW + ci * d.s_ci + tp * d.s_t;
+            o[(co + 0) * d.s_co] = t4.x * d.scale;
+            if (vec) {
+                o[(co + 1) * d.s_co] = t4.y * d.scale;
+                o[(co + 2) * d.s_co] = t4.z * d.scale;
+                o[(co + 3) * d.s_co] = t4.w * d.scale;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int umi_wgrad_reduce_group(int n, const void* items, umi_stream_t stream) {
+    if (n <= 0 || !items) return UMI_ERR_BADARG;
+    const WgPending* it = (const WgPending*)items;
+    for (int g0 = 0; g0 < n; g0 += 16) {
+        const int cnt = n - g0 < 16 ? n - g0 : 16;
+        WgTable t;
+        int total_blk = 0;
+        for (int i = 0; i < 16; ++i) {
+            t.e[i] = it[g0 + (i < cnt ? i : 0)];
+            t.blk0[i] = total_blk;
+            if (i >= cnt) continue;                              // (padding entries own no workgroups)
+            if (!t.e[i].part || !t.e[i].dW || t.e[i].splits <= 0) return UMI_ERR_BADARG;
+            const bool vec = t.e[i].Co % 4 == 0 && (((uintptr_t)t.e[i].part) & 15) == 0;
+            long g = ((long)t.e[i].RS * t.e[i].Ci * t.e[i].Co / (vec ? 4 : 1) + 31) / 32;
+            total_blk += (int)(g > 4096 ? 4096 : g);
+        }
+        t.blk0[16] = total_blk;
+        hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)total_blk), dim3(256), 0, (hipStream_t)stream, t);
+        UMI_LAUNCH_CHECK();
+    }
+    return UMI_OK;
 }
 
 static void wgrad_generic_plan(long P, int Ci, int Co, int RS, int* splits, long* chunk) {

@@ -25,6 +25,10 @@ def _fuse_bnred():
     return os.environ.get("UMI_NO_BNRED_FUSION") != "1"          # tuning / A-B knob, read per call
 
 
+def _defer_wgrad_reduce():
+    return os.environ.get("UMI_NO_WGRAD_REDUCE_GROUP") != "1"    # A/B knob, read per call
+
+
 def _fuse_bnapply(Ci):
     """Stage 3 of a conv's BatchNorm backward inside its weight-gradient kernel?  Every input-channel tile (64) of that kernel
     repeats the elementwise work on the gradient tile it stages, so the fusion only pays with a single tile: measured per
@@ -73,7 +77,8 @@ class Tape:
         self.steps = []
         self.param_grads = {}             # id(param) -> (param, grad tensor)
         self._deferred_unscale = []       # BatchNorm parameter gradients still carrying the loss scale
-        self._nbt = []                    # num_batches_tracked counters of the BatchNorm layers run in training mode
+        self._nbt = []
+        self._wgrad_deferred = None                    # num_batches_tracked counters of the BatchNorm layers run in training mode
         self._inputs = []
 
     # ---- helpers -----------------------------------------------------------------------
@@ -246,7 +251,8 @@ class Tape:
                         fuse = False
                         ops.bn_bwd_apply(o.grad, out, tx, rstd, dbeta, dgamma)
                 if not fuse:
-                    ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad)
+                    ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad,
+                                   defer=self._wgrad_deferred if id(weight) not in self.param_grads else None)
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
@@ -294,7 +300,8 @@ class Tape:
                 inv = self.inv
                 g = o.grad
                 gw = self._new_pgrad(weight)
-                ops.conv_wgrad(a.raw, a.tx, g, None, gw, Ci * R * S, R * S, 1, inv, R, S, 1, pad)
+                ops.conv_wgrad(a.raw, a.tx, g, None, gw, Ci * R * S, R * S, 1, inv, R, S, 1, pad,
+                               defer=self._wgrad_deferred if id(weight) not in self.param_grads else None)
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
@@ -377,7 +384,8 @@ class Tape:
                     self._set_pgrad(bias, gb)
                 gw = self._new_pgrad(weight)
                 # dW[ci][co][t] = sum_p act(a)[p][ci] * g[2p+t][co]: a wgrad with the roles of x and dy swapped
-                ops.conv_wgrad(g, None, a.raw, a.tx, gw, Cout * 4, 4, 1, inv, 2, 2, 2, 0)
+                ops.conv_wgrad(g, None, a.raw, a.tx, gw, Cout * 4, 4, 1, inv, 2, 2, 2, 0,
+                               defer=self._wgrad_deferred if id(weight) not in self.param_grads else None)
                 self._set_pgrad(weight, gw)
                 if _wants_grad(a):
                     tgt = self._accumulate_target(a, g, 2, 2, 2, 0)
@@ -497,9 +505,13 @@ class Tape:
         a.grad.copy_(g)
 
     def backward(self):
+        self._wgrad_deferred = [] if (self.grad_sink is None and _defer_wgrad_reduce()) else None
         for step in reversed(self.steps):
             step()
         self.steps = []
+        if self._wgrad_deferred:
+            ops.wgrad_reduce_flush(self._wgrad_deferred)     # the split-K reductions of all layers, 16 per launch
+        self._wgrad_deferred = None
         self._finish_param_grads()
         if self._deferred_unscale:
             torch._foreach_mul_(self._deferred_unscale, self.inv)

@@ -113,7 +113,8 @@ class TUTape(Tape):
                     return
                 slot = self._wstd_slot(ent, w) if ent is not None else None
                 gws = slot[0] if slot is not None else torch.empty_like(ws)
-                ops.conv_wgrad(a.raw, a.tx, o.grad, None, gws, Ci * R * S, R * S, 1, self.inv, R, S, stride, pad)
+                ops.conv_wgrad(a.raw, a.tx, o.grad, None, gws, Ci * R * S, R * S, 1, self.inv, R, S, stride, pad,
+                               defer=self._wgrad_deferred if slot is not None else None)
                 # with a slot the standardisation's backward runs once for all convs at the end of the backward pass
                 self._set_pgrad(w, slot[1] if slot is not None else ops_tu.wstd_bwd(ws, rstd, gws))
                 if _wants_grad(a):

@@ -62,6 +62,11 @@ SIGNATURES = {
                                c_long, c_long, c_long, c_float,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "umi_conv_wgrad_deferred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                        c_long, c_long, c_long, c_float,
+                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "umi_wgrad_reduce_group": (c_int, [c_int, c_void_p, c_void_p]),
     "umi_conv_wgrad_group": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_long, c_float, c_long,
                                      c_int, c_int, c_int, c_void_p]),
     "umi_conv_wgrad_bnapply": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

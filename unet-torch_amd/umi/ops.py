@@ -613,15 +613,43 @@ def conv_wgrad_bnapply(x, txa, da, y, tx_bn, rstd, sum_dz, sum_dzx, dz, dW, s_co
     return True
 
 
-def conv_wgrad(x, txa, dy, txb, dW, s_co, s_ci, s_t, out_scale, R, S, stride, pad, flags=0):
+class _WgPending(__import__("ctypes").Structure):          # mirrors umi_wgrad_pending
+    import ctypes as _c
+    _fields_ = [("part", _c.c_void_p), ("dW", _c.c_void_p), ("s_co", _c.c_long), ("s_ci", _c.c_long), ("s_t", _c.c_long),
+                ("scale", _c.c_float), ("splits", _c.c_int), ("RS", _c.c_int), ("Ci", _c.c_int), ("Co", _c.c_int)]
+
+
+def conv_wgrad(x, txa, dy, txb, dW, s_co, s_ci, s_t, out_scale, R, S, stride, pad, flags=0, defer=None):
+    """defer: a list.  The final split-K reduction is then recorded in it (with the call's own partial-sum buffer, kept alive by
+    the list) instead of launched; wgrad_reduce_flush(defer) runs all recorded reductions, 16 per launch."""
+    import ctypes
     N, H, W, Ci, ldx = _nhwc(x)
     _, Ho, Wo, Co, lddy = _nhwc(dy)
     assert dW.dtype == torch.float32 and dW.is_contiguous()
     nb = L.fn("umi_conv_wgrad_ws_bytes")(N, Ho, Wo, Ci, Co, R, S, _dt(x), flags)
-    ws = workspace(nb, x.device)
-    L.check(L.fn("umi_conv_wgrad")(x.data_ptr(), ldx, _ptr(txa), dy.data_ptr(), lddy, _ptr(txb), dW.data_ptr(),
-                                   s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
-                                   _dt(x), flags, ws.data_ptr(), ws.numel(), _stream()), "umi_conv_wgrad")
+    if defer is None:
+        ws = workspace(nb, x.device)
+        L.check(L.fn("umi_conv_wgrad")(x.data_ptr(), ldx, _ptr(txa), dy.data_ptr(), lddy, _ptr(txb), dW.data_ptr(),
+                                       s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
+                                       _dt(x), flags, ws.data_ptr(), ws.numel(), _stream()), "umi_conv_wgrad")
+        return
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=x.device)
+    pend = _WgPending()
+    L.check(L.fn("umi_conv_wgrad_deferred")(x.data_ptr(), ldx, _ptr(txa), dy.data_ptr(), lddy, _ptr(txb), dW.data_ptr(),
+                                            s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo,
+                                            _dt(x), flags, ws.data_ptr(), ws.numel(), ctypes.addressof(pend), _stream()),
+            "umi_conv_wgrad_deferred")
+    if pend.part:
+        defer.append((pend, ws, dW))
+
+
+def wgrad_reduce_flush(defer):
+    """Run the reductions recorded by conv_wgrad(defer=...) and empty the list."""
+    import ctypes
+    if defer:
+        arr = (_WgPending * len(defer))(*[d[0] for d in defer])
+        L.check(L.fn("umi_wgrad_reduce_group")(len(defer), ctypes.addressof(arr), _stream()), "umi_wgrad_reduce_group")
+        del defer[:]
 
 
 def conv_wgrad_group(xs, dys, dWs, s_co, s_ci, out_scale):
