@@ -49,12 +49,10 @@ enum { UMI_CONV_UPSAMPLE2 = 1,   /* ConvTranspose2d(k=2,s=2): tap t=(dy,dx) scat
 int umi_version(void);
 const char* umi_arch(void);          /* "gfx950" */
 
-/* Tuning knob (process-wide): which kernel serves the 3x3 / stride-1 matrix-core path of umi_conv_fwd and
- * umi_conv_dgrad_bnred: 1 = csrc/conv_mfma.hip, 2 / 3 / 4 = csrc/conv_mfma2.hip (halo staged after tap column 0 / 1 /
- * paired chunk loads), 5 = csrc/conv_mfma3.hip (persistent workgroups), 6 = csrc/conv_mfma4.hip (persistent, 8 waves in anti-phase).  All produce bit-identical outputs; only the
- * statistics partial-row count reported by umi_conv_fwd_plan differs, so change it between whole convolutions only.  Returns
- * the previous value; values outside 1..6 only query.  The initial value is
- * the library default or env UMI_CONV3X3_IMPL. */
+/* Tuning knob (process-wide): which schedule of csrc/conv_mfma.hip serves the 3x3 / stride-1 matrix-core path of umi_conv_fwd
+ * and umi_conv_dgrad_bnred: 1 = the round-1 schedule, 2 = branch-free staging + pinned fragment-read / MFMA interleave (the
+ * default), 3 = 2 with a staggered start of the two workgroups of a CU.  All produce bit-identical outputs.  Returns the
+ * previous value; values outside 1..3 only query.  The initial value is the library default or env UMI_CONV3X3_IMPL. */
 int umi_tune_conv3x3_impl(int impl);
 
 /* Re-layout of a weight tensor into the kernels' [T][K][N] packing (dtype storage):

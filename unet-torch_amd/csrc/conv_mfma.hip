@@ -72,7 +72,11 @@ struct Cfg {
 //          BatchNorm backward without re-reading the gradient tensor.
 struct BnRed { const half_t* y; int ld; const float4* tx; const float* rstd; };
 
-template <int TH, int BN, bool HAS_TX, int EPI>
+// OPT 0: the round-1 schedule.  OPT 1 (round 3): branch-free staging (padding / surplus pieces go to a dummy LDS address fixed in
+// the prologue, weight-piece validity folded into a per-lane base offset, the tap step in the scalar offset) and a pinned
+// ds_read / MFMA interleave in the MFMA phase (fragment reads issued two MFMA pairs ahead of their use instead of
+// "read, wait lgkmcnt(0), 4 MFMAs").  Same MFMA order, bit-identical outputs.
+template <int TH, int BN, bool HAS_TX, int EPI, int OPT>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     half_t* __restrict__ y, int ldy, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x,
@@ -92,6 +96,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     UMI_T(t_start);
 #endif
 
+    if (OPT == 2) {
+        // experiment: the two workgroups of a CU start together and so reach their prologues, staging phases and epilogues
+        // together.  The workgroup whose wave 0 sits in an odd wave slot waits half a workgroup lifetime, once, in the first
+        // round of the launch; successors inherit the offset.
+        if (blockIdx.x < 512) {
+            __shared__ int stag;
+            if (tid == 0) {
+                unsigned hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                stag = (int)(hwid & 1u);
+            }
+            __syncthreads();
+            if (stag) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                const unsigned long long wait = 6000ull + 1400ull * (unsigned)(Ci >> 4);
+                while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+            }
+        }
+    }
     // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so id -> work item
     // is permuted to give every XCD a contiguous range of (pixel tile, channel block) items: the channel blocks of one
     // pixel tile then share an L2 and the input tile crosses the fabric once instead of once per channel block
@@ -129,6 +152,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(x + (long)n * H * W * ldx), 0, (int)((long)H * W * ldx * 2), 0x00020000);
     const int hl_base = srow * ROWB + q * 16;                 // + k * 128 * ROWB
+    // OPT 1: the LDS byte address every halo piece is stored at, chunk after chunk.  Pieces outside the image (zero padding)
+    // and surplus pieces (hp >= HALO_PIX) are stored -- transformed garbage and all -- into the 16 pad bytes of a row, which
+    // nothing reads; the padding slots themselves are zeroed once, here, and never written again.
+    int hl[C::KPH];
+    if (OPT >= 1) {
+#pragma unroll
+        for (int k = 0; k < C::KPH; ++k) {
+            const int hp = srow + 128 * k;
+            const int hpc = hp < C::HALO_PIX ? hp : C::HALO_PIX - 1;
+            hl[k] = hoff[k] != OOB ? hp * ROWB + q * 16 : hpc * ROWB + 32;
+            if (hp < C::HALO_PIX && hoff[k] == OOB) {
+                half8 z;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = (half_t)0.f;
+                *reinterpret_cast<half8*>(smem + hp * ROWB + q * 16) = z;
+            }
+        }
+    }
     // weight piece k: row rc = (tid>>1) + 128k of the [9*BN] rows -> tap = k*(128/BN) + (tid>>1)/BN
     constexpr int TSTEP = 128 / BN;
     const int tap0 = srow / BN, wcol = srow % BN;
@@ -136,9 +177,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const int Ci8 = Ci >> 3;
     const unsigned wbase = (unsigned)(((tap0 * Ci8 + q) * Co + wcol) * 16);
     const unsigned wstep = (unsigned)(TSTEP * Ci8 * Co * 16);   // bytes per k step
+    const int wstep_s = __builtin_amdgcn_readfirstlane((int)wstep);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(wp8 + (long)c0 * 8), 0, (int)((long)9 * Ci * Co * 2 - (long)c0 * 16), 0x00020000);
     const int wl_base = C::HB + srow * ROWB + q * 16;          // + k * 128 * ROWB
+    // OPT 1: validity of a weight piece is a property of the lane (channel past Co) except for the last piece of the BN = 64
+    // tile (tap 8 + tap0), so it lives in the per-lane base offset; WBAD + any tap step stays beyond the buffer's range.
+    constexpr unsigned WBAD = 0x40000000u;
+    constexpr bool W_LAST_PARTIAL = (C::KPW - 1) * TSTEP + (TSTEP - 1) >= 9;      // BN = 64: piece 4 exists for tap0 = 0 only
+    const unsigned wbase_v = wok ? wbase : WBAD;
+    const unsigned wbase_l = (wok && tap0 + (C::KPW - 1) * TSTEP < 9) ? wbase : WBAD;
+    const int wl_last = (tap0 + (C::KPW - 1) * TSTEP < 9) ? wl_base + (C::KPW - 1) * 128 * ROWB : C::HB + srow * ROWB + 32;
 
     floatx16 acc[2][4];
 #pragma unroll
@@ -154,9 +203,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     do {                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < C::KPH; ++k)                                                        \
             hraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[k], (c_) * 32, 0)); \
-        _Pragma("unroll") for (int k = 0; k < C::KPW; ++k)                                                        \
-            wraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                            \
-                wrs, (wok && tap0 + k * TSTEP < 9) ? wbase + k * wstep : OOB, (c_) * 2 * Co * 16, 0));            \
+        if (OPT >= 1) {                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < C::KPW; ++k)                                                    \
+                wraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                        \
+                    wrs, (W_LAST_PARTIAL && k == C::KPW - 1) ? wbase_l : wbase_v,                                 \
+                    (c_) * 2 * Co * 16 + k * wstep_s, 0));                                                        \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < C::KPW; ++k)                                                    \
+                wraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                        \
+                    wrs, (wok && tap0 + k * TSTEP < 9) ? wbase + k * wstep : OOB, (c_) * 2 * Co * 16, 0));        \
+        }                                                                                                         \
     } while (0)
 
     // fragment base addresses (bytes)
@@ -168,17 +224,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     // (Rotating the chunk order per workgroup to spread the weight reads over L2 channels was measured and is
     //  SLOWER: -12 % on 1024->1024; simultaneous readers of one panel share L2 lines.)
 #define UMI_CHUNK(i_) (i_)
+    // OPT 1: the transform rows are handled by the whole of wave 0 (4 lanes per row, same value): a scalar branch, no
+    // exec-mask juggling in the loop
+    const bool tx_wave = OPT >= 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) == 0 : tid < 16;
+    const int txi = OPT >= 1 ? (lane & 15) : tid;                      // row of the chunk this thread carries
+    const int txs = (txi & 7) * 2 + (txi >> 3);                        // its slot: [j][q]
     if (HAS_TX) {
-        if (tid < 16) {
+        if (tx_wave) {
             // stored transposed ([j][q]: the two channel halves of a chunk side by side) so that the per-chunk reads of
             // lanes q = 0 / 1 fall on different LDS banks
-            txbuf[0][(tid & 7) * 2 + (tid >> 3)] = tx[tid];
-            if (nchunks > 1) txbuf[1][(tid & 7) * 2 + (tid >> 3)] = tx[16 + tid];
+            txbuf[0][txs] = tx[txi];
+            if (nchunks > 1) txbuf[1][txs] = tx[16 + txi];
         }
         __syncthreads();
     }
     UMI_ISSUE(UMI_CHUNK(0));
-    if (HAS_TX && nchunks > 2 && tid < 16) txr = tx[2 * 16 + tid];
+    if (HAS_TX && nchunks > 2 && tx_wave) txr = tx[2 * 16 + txi];
 #ifdef UMI_STAMP
     unsigned long long seg[5] = {0, 0, 0, 0, 0};
     UMI_T(t_loop);
@@ -197,18 +258,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             for (int j = 0; j < 8; ++j) t[j] = txbuf[ci_ & 1][j * 2 + q];
 #pragma unroll
             for (int k = 0; k < C::KPH; ++k) {
-                if (hoff[k] != OOB) {
+                if (OPT >= 1) hraw[k] = umi_tx8(hraw[k], t);
+                else if (hoff[k] != OOB) {
                     hraw[k] = umi_tx8(hraw[k], t);
                 }
             }
         }
 #ifndef UMI_EXP_NO_STAGE
+        if (OPT >= 1) {
+#pragma unroll
+            for (int k = 0; k < C::KPH; ++k) *reinterpret_cast<half8*>(smem + hl[k]) = hraw[k];
+#pragma unroll
+            for (int k = 0; k < C::KPW; ++k)
+                *reinterpret_cast<half8*>(smem + ((W_LAST_PARTIAL && k == C::KPW - 1) ? wl_last : wl_base + k * 128 * ROWB)) = wraw[k];
+        } else {
 #pragma unroll
         for (int k = 0; k < C::KPH; ++k)
             if (srow + 128 * k < C::HALO_PIX) *reinterpret_cast<half8*>(smem + hl_base + k * 128 * ROWB) = hraw[k];
 #pragma unroll
         for (int k = 0; k < C::KPW; ++k)
             if (tap0 + k * TSTEP < 9) *reinterpret_cast<half8*>(smem + wl_base + k * 128 * ROWB) = wraw[k];
+        }
 #else
 #pragma unroll
         for (int k = 0; k < C::KPH; ++k) asm volatile("" ::"v"(hraw[k]));
@@ -222,9 +292,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #ifdef UMI_STAMP
         UMI_T(t2);
 #endif
-        if (HAS_TX && tid < 16 && ci_ + 2 < nchunks) {
-            txbuf[ci_ & 1][(tid & 7) * 2 + (tid >> 3)] = txr;                        // every thread is past its reads of this buffer (barrier above)
-            if (ci_ + 3 < nchunks) txr = tx[(ci_ + 3) * 16 + tid];
+        if (HAS_TX && tx_wave && ci_ + 2 < nchunks) {
+            txbuf[ci_ & 1][txs] = txr;                        // every thread is past its reads of this buffer (barrier above)
+            if (ci_ + 3 < nchunks) txr = tx[(ci_ + 3) * 16 + txi];
         }
         if (ci_ + 1 < nchunks) UMI_ISSUE(UMI_CHUNK(ci_ + 1));
 
@@ -253,6 +323,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             }
         }
 #endif
+        if (OPT >= 1) {
+            // issue order of the phase's 36 fragment reads and 72 MFMAs: 8 reads up front, then one read behind every MFMA pair
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i_ = 0; i_ < 28; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
 #ifdef UMI_STAMP
         UMI_T(t3);
@@ -323,30 +403,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             for (int jj = 0; jj < 8; ++jj) { t[jj] = bn.tx[c0 + j * 8 + jj]; rs_[jj] = bn.rstd[c0 + j * 8 + jj]; }
             yb = bn.y + ((long)((long)n * H + ty0) * W + tx0) * bn.ld + c0 + j * 8;
         }
+        // one pixel of the pass: LDS -> global, and the epilogue reduction on the values on their way out
+#define UMI_EPI_PIXEL(k_)                                                                                              \
+        do {                                                                                                          \
+            const int p = p0 + (k_) * PSTEP;                                                                          \
+            const int row = p >> 5, col = p & 31;                                                                     \
+            uint4 v = *reinterpret_cast<const uint4*>(sbase + (k_) * PSTEP * C::ERS);                                 \
+            *reinterpret_cast<uint4*>(ybase + ((long)row * W + col) * ldy) = v;                                       \
+            if (EPI == 1) {                                                                                           \
+                const half8 hv = __builtin_bit_cast(half8, v);                                                        \
+                _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) { float f = (float)hv[jj]; s[jj] += f; s2[jj] = fmaf(f, f, s2[jj]); } \
+            } else if (EPI == 2) {                                                                                    \
+                const half8 hv = __builtin_bit_cast(half8, v);                                                        \
+                const half8 yv = *reinterpret_cast<const half8*>(yb + ((long)row * W + col) * bn.ld);                 \
+                _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                                    \
+                    const float yy = (float)yv[jj];                                                                   \
+                    const float dz = umi_tx_pre(yy, t[jj]) > t[jj].w ? (float)hv[jj] : 0.f;                           \
+                    s[jj] += dz;                                                                                      \
+                    s2[jj] = fmaf(dz, (yy - t[jj].x) * rs_[jj], s2[jj]);                                              \
+                }                                                                                                     \
+            }                                                                                                         \
+        } while (0)
+        // OPT 1: whole tiles (the benchmark's case) take a branch-free, fully unrolled pass: the 16 LDS reads go out together
+        const bool whole = OPT >= 1 && __builtin_amdgcn_readfirstlane((int)(full_tile && cvalid == BN)) != 0;
+        if (whole) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) UMI_EPI_PIXEL(k);
+        } else {
 #pragma unroll 8
-        for (int k = 0; k < NK; ++k) {
-            const int p = p0 + k * PSTEP;
-            const int row = p >> 5, col = p & 31;
-            if (col_ok && (full_tile || (ty0 + row < H && tx0 + col < W))) {
-                uint4 v = *reinterpret_cast<const uint4*>(sbase + k * PSTEP * C::ERS);
-                *reinterpret_cast<uint4*>(ybase + ((long)row * W + col) * ldy) = v;
-                if (EPI == 1) {
-                    const half8 hv = __builtin_bit_cast(half8, v);
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) { float f = (float)hv[jj]; s[jj] += f; s2[jj] = fmaf(f, f, s2[jj]); }
-                } else if (EPI == 2) {
-                    const half8 hv = __builtin_bit_cast(half8, v);
-                    const half8 yv = *reinterpret_cast<const half8*>(yb + ((long)row * W + col) * bn.ld);
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const float yy = (float)yv[jj];
-                        const float dz = umi_tx_pre(yy, t[jj]) > t[jj].w ? (float)hv[jj] : 0.f;
-                        s[jj] += dz;
-                        s2[jj] = fmaf(dz, (yy - t[jj].x) * rs_[jj], s2[jj]);
-                    }
-                }
+            for (int k = 0; k < NK; ++k) {
+                const int p_ = p0 + k * PSTEP;
+                if (col_ok && (full_tile || (ty0 + (p_ >> 5) < H && tx0 + (p_ & 31) < W))) UMI_EPI_PIXEL(k);
             }
         }
+#undef UMI_EPI_PIXEL
     }
 
     if (EPI == 1 || EPI == 2) {
@@ -378,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #endif
 }
 
-template <int TH, int BN>
+template <int TH, int BN, int OPT>
 int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H, int W,
            int Ci, int Co, const BnRed* bnred, hipStream_t s, const void* out_tx = nullptr) {
     const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = (Co + BN - 1) / BN;
@@ -388,7 +478,7 @@ int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int
     const int xcd_chunk = (n_co > 1 && !xcd_off) ? (int)(nblk / 8) : 0;     // ids beyond 8 * chunk (the remainder) keep their order
     const BnRed bn = bnred ? *bnred : BnRed{nullptr, 0, (const float4*)out_tx, nullptr};
 #define GO(HT, EP)                                                                                               \
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, EP>), grid, block, 0, s, (const half_t*)x, ldx,          \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, EP, OPT>), grid, block, 0, s, (const half_t*)x, ldx,          \
                        (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
                        tiles_y, n_co, xcd_chunk, bn)
     if (out_tx) { if (tx) GO(true, 3); else GO(false, 3); }
@@ -421,77 +511,54 @@ static bool use_bn128(int Co) { (void)Co; return false; }
 static bool use_bn128(int Co) { return Co % 128 == 0; }
 #endif
 
-// conv_mfma2.hip: the second-generation kernel (LDS-DMA weights, double-buffered LDS), bit-identical outputs
-int umi_conv3x3_mfma2_stat_rows(int N, int H, int W);
-int umi_conv3x3_mfma2(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H,
-                      int W, int Ci, int Co, const void* bn_y, int bn_ld, const void* bn_tx, const float* bn_rstd,
-                      int variant, hipStream_t s);
-
-// conv_mfma3.hip: persistent workgroups (tile-boundary-free chunk stream, wave-private epilogue), bit-identical outputs
-int umi_conv3x3_mfma3_stat_rows(int N, int H, int W);
-bool umi_conv3x3_mfma3_ok(int N, int H, int W, int Ci, int Co, int ldx);
-int umi_conv3x3_mfma3(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H,
-                      int W, int Ci, int Co, const void* bn_y, int bn_ld, const void* bn_tx, const float* bn_rstd,
-                      hipStream_t s);
-
-// conv_mfma4.hip: persistent 8-wave workgroups, two wave groups in anti-phase, bit-identical outputs
-int umi_conv3x3_mfma4_stat_rows(int N, int H, int W);
-bool umi_conv3x3_mfma4_ok(int N, int H, int W, int Ci, int Co, int ldx);
-int umi_conv3x3_mfma4(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H,
-                      int W, int Ci, int Co, const void* bn_y, int bn_ld, const void* bn_tx, const float* bn_rstd,
-                      hipStream_t s);
-
-// Which kernel serves the 3x3 MFMA path: 1 = conv_mfma.hip, 2 / 3 / 4 = conv_mfma2.hip (variants), 5 = conv_mfma3.hip
-// (persistent), 6 = conv_mfma4.hip (persistent, 8 waves in anti-phase); shapes 5 / 6 do not take fall back to 1.  Process-wide tuning
-// knob (env UMI_CONV3X3_IMPL at load, umi_tune_conv3x3_impl at run time for same-process A/B timing); the statistics
-// partial-row count of umi_conv_fwd_plan follows it, so set it between whole convolutions only.
-static int g_impl = [] { const char* e = getenv("UMI_CONV3X3_IMPL"); return e ? atoi(e) : 1; }();
+// Which schedule serves the 3x3 MFMA path: 1 = the round-1 schedule (OPT 0), 2 = branch-free staging + pinned read / MFMA
+// interleave (OPT 1), 3 = 2 + staggered start of the two workgroups of a CU (OPT 2, experiment).  Bit-identical outputs.  Process-wide tuning knob (env UMI_CONV3X3_IMPL at load,
+// umi_tune_conv3x3_impl at run time for same-process A/B timing).  The rejected round-2 restructurings (LDS-DMA weights,
+// persistent workgroups, 8-wave anti-phase) live in tools/experiments/conv_variants/ with the A/B files that retired them.
+static int g_impl = [] { const char* e = getenv("UMI_CONV3X3_IMPL"); return e ? atoi(e) : 2; }();
 extern "C" int umi_tune_conv3x3_impl(int impl) {
     const int old = g_impl;
-    if (impl >= 1 && impl <= 6) g_impl = impl;
+    if (impl >= 1 && impl <= 3) g_impl = impl;
     return old;
 }
 
 static int pick_th(int Co) { return use_bn128(Co) ? 8 : 16; }
 
 int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Ci, int Co, int ldx) {
-    if (g_impl == 6 && umi_conv3x3_mfma4_ok(N, H, W, Ci, Co, ldx)) return umi_conv3x3_mfma4_stat_rows(N, H, W);
-    if (g_impl == 5 && umi_conv3x3_mfma3_ok(N, H, W, Ci, Co, ldx)) return umi_conv3x3_mfma3_stat_rows(N, H, W);
-    if (g_impl >= 2 && g_impl <= 4) return umi_conv3x3_mfma2_stat_rows(N, H, W);
     const int th = pick_th(Co);
     return N * ((W + 31) / 32) * ((H + th - 1) / th);
 }
 
+#define UMI_GO(...)                                                                          \
+    do {                                                                                     \
+        if (g_impl == 1) {                                                                   \
+            if (use_bn128(Co)) return launch<8, 128, 0>(__VA_ARGS__);                        \
+            return launch<16, 64, 0>(__VA_ARGS__);                                           \
+        }                                                                                    \
+        if (g_impl == 3) {                                                                   \
+            if (use_bn128(Co)) return launch<8, 128, 2>(__VA_ARGS__);                        \
+            return launch<16, 64, 2>(__VA_ARGS__);                                           \
+        }                                                                                    \
+        if (use_bn128(Co)) return launch<8, 128, 1>(__VA_ARGS__);                            \
+        return launch<16, 64, 1>(__VA_ARGS__);                                               \
+    } while (0)
+
 int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
                      int N, int H, int W, int Ci, int Co, hipStream_t s) {
-    if (g_impl == 6 && umi_conv3x3_mfma4_ok(N, H, W, Ci, Co, ldx))
-        return umi_conv3x3_mfma4(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, 0, nullptr, nullptr, s);
-    if (g_impl == 5 && umi_conv3x3_mfma3_ok(N, H, W, Ci, Co, ldx))
-        return umi_conv3x3_mfma3(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, 0, nullptr, nullptr, s);
-    if (g_impl >= 2 && g_impl <= 4)
-        return umi_conv3x3_mfma2(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, 0, nullptr, nullptr, g_impl - 2, s);
-    if (use_bn128(Co)) return launch<8, 128>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, s);
-    return launch<16, 64>(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, s);
+    UMI_GO(x, ldx, tx, wp8, y, ldy, stat_part, N, H, W, Ci, Co, nullptr, s);
 }
 
 // data gradient + stage 1 of the BatchNorm backward of the layer whose activated-output gradient it produces (EPI 2)
 int umi_conv3x3_mfma_bnred(const void* dy, int lddy, const void* wp8, void* da, int ldda, const void* ybn, int ldybn,
                            const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
                            hipStream_t s) {
-    if (g_impl == 6 && umi_conv3x3_mfma4_ok(N, H, W, Ci, Co, lddy))
-        return umi_conv3x3_mfma4(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, ybn, ldybn, txbn, rstd, s);
-    if (g_impl == 5 && umi_conv3x3_mfma3_ok(N, H, W, Ci, Co, lddy))
-        return umi_conv3x3_mfma3(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, ybn, ldybn, txbn, rstd, s);
-    if (g_impl >= 2 && g_impl <= 4)
-        return umi_conv3x3_mfma2(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, ybn, ldybn, txbn, rstd, g_impl - 2, s);
     const BnRed bn{(const half_t*)ybn, ldybn, (const float4*)txbn, rstd};
-    if (use_bn128(Co)) return launch<8, 128>(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, &bn, s);
-    return launch<16, 64>(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, &bn, s);
+    UMI_GO(dy, lddy, nullptr, wp8, da, ldda, part, N, H, W, Ci, Co, &bn, s);
 }
 
-// inference: conv + this layer's BatchNorm (running statistics) + ReLU on store (EPI 3); always the round-1 kernel
+// inference: conv + this layer's BatchNorm (running statistics) + ReLU on store (EPI 3)
 int umi_conv3x3_mfma_act(const void* x, int ldx, const void* tx, const void* wp8, const void* out_tx, void* y, int ldy, int N,
                          int H, int W, int Ci, int Co, hipStream_t s) {
-    if (use_bn128(Co)) return launch<8, 128>(x, ldx, tx, wp8, y, ldy, nullptr, N, H, W, Ci, Co, nullptr, s, out_tx);
-    return launch<16, 64>(x, ldx, tx, wp8, y, ldy, nullptr, N, H, W, Ci, Co, nullptr, s, out_tx);
+    UMI_GO(x, ldx, tx, wp8, y, ldy, nullptr, N, H, W, Ci, Co, nullptr, s, out_tx);
 }
+#undef UMI_GO
