@@ -49,10 +49,9 @@ enum { UMI_CONV_UPSAMPLE2 = 1,   /* ConvTranspose2d(k=2,s=2): tap t=(dy,dx) scat
 int umi_version(void);
 const char* umi_arch(void);          /* "gfx950" */
 
-/* Tuning knob (process-wide): which schedule of csrc/conv_mfma.hip serves the 3x3 / stride-1 matrix-core path of umi_conv_fwd
- * and umi_conv_dgrad_bnred: 1 = the round-1 schedule, 2 = branch-free staging + pinned fragment-read / MFMA interleave (the
- * default), 3 = 2 with a staggered start of the two workgroups of a CU.  All produce bit-identical outputs.  Returns the
- * previous value; values outside 1..3 only query.  The initial value is the library default or env UMI_CONV3X3_IMPL. */
+/* Experiment knob (process-wide) for same-process A/B timing of variants of csrc/conv_mfma.hip (tools/ab_conv.py with libraries
+ * from tools/build_variant.py): the shipped library has one conv3x3 matrix-core kernel and ignores the value.  Returns the
+ * previous value; values outside 1..8 only query.  Initial value: 1 or env UMI_CONV3X3_IMPL. */
 int umi_tune_conv3x3_impl(int impl);
 
 /* Re-layout of a weight tensor into the kernels' [T][K][N] packing (dtype storage):

@@ -27,12 +27,9 @@
 //     MFMA pair, so a read is in flight for >= 4 MFMAs before its use.  hipcc's own order was "read, s_waitcnt lgkmcnt(0),
 //     4 MFMAs": one exposed LDS latency per 128 matrix-pipe cycles;
 //   * whole tiles take a branch-free, fully unrolled store pass in the epilogue;
-//   * measured and NOT kept (tools/experiments/conv_variants/conv_mfma_persist.hip, profiles/r03_conv_fwd_persistent_*): persistent
-//     workgroups (2 per CU) that prefetch the next tile's first chunk behind the epilogue's store pass.  With a static tile
-//     order the workgroup lifetimes of a launch spread by +-15 % and the launch lasts as long as the slowest; with tiles drawn
-//     from per-XCD counters the lifetimes even out and the launch is still 2-10 % slower than one workgroup per tile: issuing
-//     the prefetch's 10-12 loads blocks for 1.5-6 k cycles behind the epilogue stores of the CU, which the hardware's own
-//     dispatch of a fresh workgroup hides just as well.
+//   * PERSIST: a workgroup walks several tiles (grid = 2 x CUs) and issues the next tile's first chunk of loads as soon as
+//     the accumulators have left for the LDS tile, so the tile prologue's global round trip (6-13 k cycles on the 64 /
+//     128-channel layers, a quarter of a workgroup's life there) runs behind the epilogue's store pass.
 //
 // Epilogue: accumulators -> fp16 -> LDS tile [pixel][BN] -> coalesced 16-B global stores, and the
 // per-channel sum / sum-of-squares of the *stored* values (BatchNorm statistics) are taken column-wise
@@ -102,17 +99,18 @@ __device__ __forceinline__ void* umi_uniform_ptr(const void* p) {
 // one work item = (pixel tile, output-channel block)
 struct Tile { int n, ty0, tx0, c0, cvalid, pt; };
 
-template <int TH, int BN, bool HAS_TX, int EPI>
+template <int TH, int BN, bool HAS_TX, int EPI, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     half_t* __restrict__ y, int ldy, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x,
-    int tiles_y, int n_co, int xcd_chunk, BnRed bn) {
+    int tiles_y, int n_co, int xcd_chunk, int nitems, int* __restrict__ sched, BnRed bn) {
     using C = Cfg<TH, BN>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];
     // consumer-transform rows of the current / next chunk (16 channels x float4), refilled two chunks ahead so the
     // transform never waits on a global load (measured with in-kernel stamps: 8 dependent tx loads per chunk cost
     // ~1,650 of the ~7,200 cycles of a main-loop iteration)
     __shared__ float4 txbuf[2][16];
+    __shared__ int s_next;                          // PERSIST: the work item this workgroup drew for its next tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -230,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     } while (0)
 
     // the transform rows are carried by the whole of wave 0 (4 lanes per row, same value): a scalar branch, no exec-mask
-    // juggling in the loop.  txbuf[c & 1] holds the rows of chunk c, txr those of chunk c + 2 (indices wrap: the surplus loads
-    // of the last two chunks read rows that exist).
+    // juggling in the loop.  The rows rotate cyclically over the chunks (a persistent workgroup's next tile starts at chunk 0
+    // again): txbuf[g & 1] holds the rows of global chunk step g, txr those of step g + 2.
     const bool tx_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     const int txi = lane & 15;                                          // row of the chunk this thread carries
     const int txs = (txi & 7) * 2 + (txi >> 3);                         // its slot, [j][q]: the two channel halves of a chunk
@@ -239,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     float4 txr = make_float4(0.f, 1.f, 0.f, 0.f);
     int txc = 0;                                                        // chunk whose rows txr holds
 
-    const Tile cur = decode(blockIdx.x);
+    int item = blockIdx.x;
+    Tile cur = decode(item);
     UMI_PLAN(cur);
     UMI_ISSUE(0);                       // first: the prologue's one global round trip covers the transform rows as well
     UMI_ZERO_PADDING();
@@ -252,7 +251,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         }
         __syncthreads();
     }
-    {
+    unsigned gstep = 0;                 // global chunk step of this workgroup (parity = txbuf buffer)
+
+    // PERSIST: after its first (static) tile a workgroup draws further tiles from a counter, one counter per XCD class
+    // (blockIdx & 7: the workgroups of one XCD under round-robin placement -- speed only), so the XCD-aware item order
+    // survives and the workgroups of an XCD balance one another: with a static round-robin the workgroup lifetimes of a
+    // launch spread by +-15 % (64 -> 64 at 512 x 512: 572 k .. 788 k cycles) and the launch lasts as long as the slowest.
+    // Class x owns items x, x + 8, x + 16, ...; its first gridDim / 8 are the static ones.
+    const bool dynamic = PERSIST && nitems > (int)gridDim.x;
+    const int xclass = blockIdx.x & 7;
+    for (;;) {
+        int drawn = 0;
+        if (dynamic && tid == 0)
+            drawn = __hip_atomic_fetch_add(sched + xclass, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // back long before the epilogue
+        int next_item = nitems;
+        bool has_next = false;
+        Tile nxt = cur;
+
         floatx16 acc[2][4];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         UMI_T(t_loop);
         if (n_chunks_done == 0) t_pro = t_loop - t_start;
 #endif
-        for (int ci_ = 0; ci_ < nchunks; ++ci_) {
+        for (int ci_ = 0; ci_ < nchunks; ++ci_, ++gstep) {
 #ifdef UMI_STAMP
             UMI_T(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             if (HAS_TX) {
                 float4 t[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = txbuf[ci_ & 1][j * 2 + q];
+                for (int j = 0; j < 8; ++j) t[j] = txbuf[gstep & 1][j * 2 + q];
 #pragma unroll
                 for (int k = 0; k < C::KPH; ++k) hraw[k] = umi_tx8(hraw[k], t);
             }
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             UMI_T(t2);
 #endif
             if (HAS_TX && tx_wave) {
-                txbuf[ci_ & 1][txs] = txr;            // every thread is past its reads of this buffer (barrier above)
+                txbuf[gstep & 1][txs] = txr;            // every thread is past its reads of this buffer (barrier above)
                 txc = txc + 1 < nchunks ? txc + 1 : 0;
                 txr = tx[txc * 16 + txi];
             }
@@ -371,7 +386,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                     *reinterpret_cast<half4*>(smem + pix * C::ERS + co * 2) = h;
                 }
             }
+        if (dynamic && tid == 0) s_next = xclass + 8 * ((int)(gridDim.x >> 3) + drawn);
         __syncthreads();
+        if (dynamic) {
+            next_item = __builtin_amdgcn_readfirstlane(s_next);
+            has_next = next_item < nitems;
+        }
 #ifdef UMI_STAMP
         UMI_T(t_e1);
         eps[0] += t_e1 - t_ep0;
@@ -419,10 +439,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             // whole tiles (the benchmark's case) take a branch-free, fully unrolled pass through buffer descriptors: pixel
             // p = p0 + k * PSTEP is row (k * PSTEP) >> 5, column p0 + ((k * PSTEP) & 31) of the tile, so the k-dependent part
             // of the address is a scalar offset (no 64-bit address per store, no registers held across the tile loop)
-            const bool whole = __builtin_amdgcn_readfirstlane((int)(full_tile && cvalid == BN)) != 0;
+            // (a persistent launch is only made for shapes without partial tiles: its kernel has no other store path)
+            const bool whole = PERSIST || __builtin_amdgcn_readfirstlane((int)(full_tile && cvalid == BN)) != 0;
             const long tile_pix = ((long)n * H + ty0) * W + tx0;
             half_t* ybase = y + tile_pix * ldy + c0 + j * 8;
-            // (1) EPI 2: the BatchNorm layer's raw outputs for this thread's 16 pixels, all loads up front
+            // (1) EPI 2: the BatchNorm layer's raw outputs for this thread's 16 pixels.  All of them go out before the next
+            //     tile's prefetch: loads return in order, a load behind the prefetch would wait for all of it.
             half8 yv[NK];
             if (EPI == 2 && whole) {
                 const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(umi_uniform_ptr(bn.y + tile_pix * bn.ld + c0), 0, 0x7FFFF000, 0x00020000);
@@ -432,11 +454,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                     yv[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
                         brs, bvo, ((((k * PSTEP) >> 5) * W + ((k * PSTEP) & 31)) * bn.ld) * 2, 0));
             }
+            // (2) the next tile's first chunk: its global round trip runs behind the store pass below (the accumulators are
+            //     dead from here on; issuing it before the last MFMA phase instead costs the chunk loop spilled registers).
+            //     ONE issue site: two (one per branch below) end in register copies at the loop's back edge, i.e. in a wait.
+            if (has_next) {
+                nxt = decode(next_item);
+                UMI_PLAN(nxt);
+                UMI_ISSUE(0);
+            }
 #ifdef UMI_STAMP
             UMI_T(t_e2);
             eps[1] += t_e2 - t_e1;
 #endif
-            // (2) LDS -> global, and the epilogue reduction on the values on their way out
+            // (3) LDS -> global, and the epilogue reduction on the values on their way out
             if (whole) {
                 const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(umi_uniform_ptr(y + tile_pix * ldy + c0), 0, 0x7FFFF000, 0x00020000);
                 const unsigned yvo = (unsigned)(p0 * ldy + j * 8) * 2u;
@@ -495,6 +525,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         UMI_T(t_end);
         t_epi += t_end - t_ep0;
 #endif
+        if (!has_next) break;
+        __syncthreads();                // every thread is done with the epilogue's LDS (and s_next): the next tile may stage into it
+        item = next_item;
+        cur = nxt;
+        UMI_ZERO_PADDING();             // of the tile whose plan is current (the chunk loop's first barrier orders it before the reads)
+    }
+    if (dynamic && tid == 0) {
+        // the last workgroup to finish re-arms the counters for the next launch that uses this slot (same stream: ordered)
+        const int done = __hip_atomic_fetch_add(sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #ifdef UMI_STAMP
     if (lane == 0 && blockIdx.x < 512) {
@@ -511,20 +554,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #endif
 }
 
-template <int TH, int BN>
+int g_persist_wgs = 0;                  // 2 x CUs, set on first use
+// tile counters of the persistent launches: 16 ints per launch slot (8 XCD classes + a "done" count), zero at load and
+// re-armed by the last workgroup of every launch; launches take slots round-robin so that two launches in flight on
+// different streams never share one (64 slots; a captured launch keeps its slot, replays are ordered on their stream)
+__device__ int g_sched[64 * 16];
+unsigned g_sched_slot = 0;
+
+template <int TH, int BN, bool PERSIST>
 int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H, int W,
            int Ci, int Co, const BnRed* bnred, hipStream_t s, const void* out_tx = nullptr) {
     const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = (Co + BN - 1) / BN;
     const long nblk = (long)N * tiles_x * tiles_y * n_co;
     if (nblk >= (1L << 31)) return UMI_ERR_UNSUPPORTED;
-    dim3 grid((unsigned)nblk), block(256);
+    long ngrid = nblk;
+    if (PERSIST) {
+        if (!g_persist_wgs) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                cus = 256;
+            g_persist_wgs = 2 * cus;
+        }
+        if (ngrid > g_persist_wgs) ngrid = g_persist_wgs;
+    }
+    int* sched = nullptr;
+    if (PERSIST) {
+        if (hipGetSymbolAddress((void**)&sched, HIP_SYMBOL(g_sched)) != hipSuccess) return UMI_ERR_UNSUPPORTED;
+        sched += 16 * (g_sched_slot++ & 63);
+        // the dynamic draw assumes whole XCD classes on both sides
+        if (ngrid < nblk && ((ngrid & 7) || (nblk & 7))) ngrid = nblk;
+    }
+    dim3 grid((unsigned)ngrid), block(256);
     static const bool xcd_off = [] { const char* e = getenv("UMI_CONV_NO_XCD_ORDER"); return e && e[0] == '1'; }();
     const int xcd_chunk = (n_co > 1 && !xcd_off) ? (int)(nblk / 8) : 0;     // ids beyond 8 * chunk (the remainder) keep their order
     const BnRed bn = bnred ? *bnred : BnRed{nullptr, 0, (const float4*)out_tx, nullptr};
 #define GO(HT, EP)                                                                                               \
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, EP>), grid, block, 0, s, (const half_t*)x, ldx, \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, EP, PERSIST>), grid, block, 0, s, (const half_t*)x, ldx, \
                        (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
-                       tiles_y, n_co, xcd_chunk, bn)
+                       tiles_y, n_co, xcd_chunk, (int)nblk, sched, bn)
     if (out_tx) { if (tx) GO(true, 3); else GO(false, 3); }
     else if (bnred) { if (tx) GO(true, 2); else GO(false, 2); }
     else if (tx) { if (part) GO(true, 1); else GO(true, 0); }
@@ -556,14 +623,15 @@ static bool use_bn128(int Co) { (void)Co; return false; }
 static bool use_bn128(int Co) { return Co % 128 == 0; }
 #endif
 
-// Tuning knob kept for same-process A/B experiments (tools/ab_conv.py): the library has ONE conv3x3 MFMA kernel; variants are
-// built with tools/build_variant.py and selected per arm.  The round-1 schedule, the round-2 restructurings (LDS-DMA weights,
-// persistent DMA-fed workgroups, 8-wave anti-phase) and the round-3 persistent form are in git history /
+// Which launch form serves the 3x3 MFMA path: 1 = one workgroup per tile, 2 = persistent workgroups (2 per CU) that prefetch
+// the next tile's first chunk.  Bit-identical outputs.  Process-wide tuning knob (env UMI_CONV3X3_IMPL at load,
+// umi_tune_conv3x3_impl at run time for same-process A/B timing).  The round-1 schedule and the rejected round-2
+// restructurings (LDS-DMA weights, persistent DMA-fed workgroups, 8-wave anti-phase) are in git history /
 // tools/experiments/conv_variants/ with the A/B files that retired them (profiles/r02_conv_fwd_ab_*, r03_conv_fwd_ab_*).
 static int g_impl = [] { const char* e = getenv("UMI_CONV3X3_IMPL"); return e ? atoi(e) : 1; }();
 extern "C" int umi_tune_conv3x3_impl(int impl) {
     const int old = g_impl;
-    if (impl >= 1 && impl <= 8) g_impl = impl;
+    if (impl >= 1 && impl <= 2) g_impl = impl;
     return old;
 }
 
@@ -576,8 +644,12 @@ int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Ci, int Co, int ldx) {
 
 #define UMI_GO(...)                                                                          \
     do {                                                                                     \
-        if (use_bn128(Co)) return launch<8, 128>(__VA_ARGS__);                               \
-        return launch<16, 64>(__VA_ARGS__);                                                  \
+        if (g_impl == 2 && W % 32 == 0 && H % pick_th(Co) == 0 && Co % (use_bn128(Co) ? 128 : 64) == 0) { \
+            if (use_bn128(Co)) return launch<8, 128, true>(__VA_ARGS__);                     \
+            return launch<16, 64, true>(__VA_ARGS__);                                        \
+        }                                                                                    \
+        if (use_bn128(Co)) return launch<8, 128, false>(__VA_ARGS__);                        \
+        return launch<16, 64, false>(__VA_ARGS__);                                           \
     } while (0)
 
 int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
