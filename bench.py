@@ -98,7 +98,7 @@ def measure_conv_roofline(device, dtype, cin, f, H, W, B, reps=5):
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE); PMC collection
     # cannot run inside this process, so the figure is read from profiles/ and null when that file is absent
     traffic, traffic_note = None, None
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_fwd_traffic.json")
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_conv_fwd_traffic.json")
     if os.path.exists(tf) and (cin, f, H, W, B) == (1, 64, 512, 512, 16):
         with open(tf) as fh:
             tj = json.load(fh)
