@@ -62,26 +62,33 @@ namespace {
 constexpr int HALO_W = 34;      // 32 + 2
 constexpr int ROWB = 48;        // LDS bytes per pixel / weight row (16 halfs + 16 B pad)
 
-template <int TH, int BN>
+// SC = 16-channel chunks per staged halo tile ("super-chunk").  SC = 2: the halo tile is staged for 32 input channels at a
+// time (64 B of every pixel's 128-B line per load instead of 32 B, every line requested half as often), the weights still per
+// 16-channel chunk.  Used by the BN = 64 tile, i.e. the 512 x 512 layers, whose input lines do not survive in the XCD's 4 MB
+// L2 from one chunk to the next (64 resident tiles x 78 KB): measured fabric-side fetch 1.87 x the input of 64 -> 64 at
+// 512 x 512 and 2.08 x for 128 -> 64 (profiles/r03_conv_fwd_traffic.json) against 1.2 x for the halo alone.
+template <int TH, int BN, int SC = 1>
 struct Cfg {
     static constexpr int WN = BN / 64;
     static constexpr int WM = 4 / WN;
     static_assert(TH / WM == 4, "every wave owns 4 image rows");
     static constexpr int HALO_PIX = (TH + 2) * HALO_W;
-    static constexpr int HB = HALO_PIX * ROWB;
+    static constexpr int NQ = 2 * SC;                // 8-channel groups per halo row
+    static constexpr int HROWB = NQ * 16 + 16;       // LDS bytes per halo pixel: data + 16 B pad (an odd number of 16-B slots)
+    static constexpr int HPASS = 256 / NQ;           // halo rows staged per pass of the 256 threads
+    static constexpr int HB = HALO_PIX * HROWB;
     static constexpr int WB = 9 * BN * ROWB;
     static constexpr int P = TH * 32;
     static constexpr int ERS = BN * 2 + 16;          // epilogue LDS row stride (bytes)
     static constexpr int EB = P * ERS;
     static constexpr int SMEM = (HB + WB) > EB ? (HB + WB) : EB;
-    static constexpr int NPH = 2 * HALO_PIX;         // 16-B pieces of the halo tile per chunk
-    static constexpr int KPH = (NPH + 255) / 256;
+    static constexpr int KPH = (HALO_PIX + HPASS - 1) / HPASS;   // 16-B halo pieces per thread and super-chunk
     static constexpr int NPW = 9 * BN * 2;           // 16-B pieces of the weights per chunk
     static constexpr int KPW = (NPW + 255) / 256;
     static constexpr int TSTEP = 128 / BN;           // taps advanced per weight piece (1 or 2)
     // BN = 64: the last piece (k = 4) is tap 8 for the lower 64 staging rows and does not exist for the upper 64
     static constexpr bool W_LAST_PARTIAL = (KPW - 1) * TSTEP + (TSTEP - 1) >= 9;
-    static constexpr int PRE = 8;                    // fragment reads issued ahead of the MFMA phase's first MFMA
+    static constexpr int PRE = SC == 2 ? 6 : 8;      // fragment reads issued ahead of the MFMA phase's first MFMA (fewer where registers are short)
 };
 
 // Epilogue reductions written as one partial row per pixel tile, part[tile][2][Co]:
@@ -102,17 +109,18 @@ __device__ __forceinline__ void* umi_uniform_ptr(const void* p) {
 // one work item = (pixel tile, output-channel block)
 struct Tile { int n, ty0, tx0, c0, cvalid, pt; };
 
-template <int TH, int BN, bool HAS_TX, int EPI>
+template <int TH, int BN, int SC, bool HAS_TX, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     half_t* __restrict__ y, int ldy, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x,
     int tiles_y, int n_co, int xcd_chunk, BnRed bn) {
-    using C = Cfg<TH, BN>;
+    using C = Cfg<TH, BN, SC>;
+    constexpr int HROWB = C::HROWB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];
     // consumer-transform rows of the current / next chunk (16 channels x float4), refilled two chunks ahead so the
     // transform never waits on a global load (measured with in-kernel stamps: 8 dependent tx loads per chunk cost
     // ~1,650 of the ~7,200 cycles of a main-loop iteration)
-    __shared__ float4 txbuf[2][16];
+    __shared__ float4 txbuf[2][16 * SC];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -129,8 +137,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     // kernel's LDS-array cycles were SQ_LDS_BANK_CONFLICT, profiles/r01_conv_fwd_lds_mfma.json); 8 lanes covering 8
     // consecutive rows of ONE half fall on 32 distinct banks.  Global coalescing is unchanged: a wave still touches the same
     // 32 rows x 32 bytes.
-    const int q = (tid >> 3) & 1;                  // which 8-channel half of the 16-channel chunk this thread stages
-    const int srow = ((tid >> 4) << 3) | (tid & 7);   // this thread's row among the 128 staged per pass
+    const int q = (tid >> 3) & 1;                  // which 8-channel half of the 16-channel chunk this thread stages (weights)
+    const int srow = ((tid >> 4) << 3) | (tid & 7);   // this thread's row among the 128 staged per pass (weights)
+    // halo: NQ 8-channel groups per row, HPASS rows per pass, same 8-consecutive-rows-per-8-lanes shape
+    const int hq = SC == 1 ? q : (tid >> 3) & (C::NQ - 1);
+    const int hrow = SC == 1 ? srow : ((tid >> 5) << 3) | (tid & 7);
 
     // weight piece k: row rc = srow + 128k of the [9*BN] rows -> tap = k * TSTEP + srow / BN
     const int tap0 = srow / BN, wcol = srow % BN;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 
     // fragment base addresses (bytes)
     const int lrow = lane & 31, lhalf = lane >> 5;
-    const int b_base = ((wm * 4) * HALO_W + lrow) * ROWB + lhalf * 16;               // + ((nt+dy)*34 + dx)*48
+    const int b_base = ((wm * 4) * HALO_W + lrow) * HROWB + lhalf * 16;              // + ((nt+dy)*34 + dx)*HROWB + sub*32
     const int a_base = C::HB + (wn * 64 + lrow) * ROWB + lhalf * 16;                 // + (tap*BN + mt*32)*48
     const int nchunks = Ci >> 4;
     // (Rotating the chunk order per workgroup to spread the weight reads over L2 channels was measured and is
@@ -154,7 +165,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     constexpr unsigned OOB = 0x7FFFFFFFu;
     constexpr unsigned WBAD = 0x40000000u;         // + any tap step stays beyond the weight buffer's range
     unsigned hoff[C::KPH];                         // byte offset inside image n, or OOB (zero padding / no piece)
-    int hl[C::KPH];                                // LDS byte address the piece is stored at: its slot, or a row's pad bytes
+    // LDS byte address a piece is stored at = its slot (hl_a + k * HPASS rows) or, outside the image, the pad bytes of that
+    // row (hl_b + ...), picked per chunk from hoff[k]; the last piece, which some threads do not have at all, keeps its own
+    int hl_a, hl_b, hl_last;
     unsigned wbase_v, wbase_l;                     // per-lane weight offset (WBAD for channels past Co / a missing last piece)
     __amdgpu_buffer_rsrc_t xrs, wrs;
 
@@ -182,19 +195,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         int tid_ = threadIdx.x;                                                                                       \
         asm volatile("" : "+v"(tid_));                                                                                \
         const int q = (tid_ >> 3) & 1, srow = ((tid_ >> 4) << 3) | (tid_ & 7);                                        \
+        const int hq = SC == 1 ? q : (tid_ >> 3) & (C::NQ - 1), hrow = SC == 1 ? srow : ((tid_ >> 5) << 3) | (tid_ & 7); \
         const int tap0 = srow / BN, wcol = srow % BN;                                                                 \
         const unsigned wbase = (unsigned)(((tap0 * (Ci >> 3) + q) * Co + wcol) * 16);                                 \
         const bool w_last_ok = tap0 + (C::KPW - 1) * C::TSTEP < 9;                                                    \
         _Pragma("unroll") for (int k = 0; k < C::KPH; ++k) {                                                          \
-            /* halo piece k of this thread: halo pixel hp = srow + 128k, channel half q */                            \
-            const int hp = srow + 128 * k;                                                                            \
+            /* halo piece k of this thread: halo pixel hp = hrow + HPASS * k, channel group hq */                     \
+            const int hp = hrow + C::HPASS * k;                                                                       \
             const int hy = hp / HALO_W, hx = hp - hy * HALO_W;                                                        \
             const int gy = (t_).ty0 + hy - 1, gx = (t_).tx0 + hx - 1;                                                 \
             const bool inimg = (hp < C::HALO_PIX) && gy >= 0 && gy < H && gx >= 0 && gx < W;                          \
-            hoff[k] = inimg ? (unsigned)(gy * W + gx) * (unsigned)(ldx * 2) + q * 16 : OOB;                           \
+            hoff[k] = inimg ? (unsigned)(gy * W + gx) * (unsigned)(ldx * 2) + hq * 16 : OOB;                          \
             const int hpc = hp < C::HALO_PIX ? hp : C::HALO_PIX - 1;                                                  \
-            hl[k] = inimg ? hp * ROWB + q * 16 : hpc * ROWB + 32;                                                     \
+            if (k == C::KPH - 1) hl_last = inimg ? hp * HROWB + hq * 16 : hpc * HROWB + C::NQ * 16;                   \
         }                                                                                                             \
+        hl_a = hrow * HROWB + hq * 16;                                                                                \
+        hl_b = hrow * HROWB + C::NQ * 16;                                                                             \
         xrs = __builtin_amdgcn_make_buffer_rsrc(umi_uniform_ptr(x + (long)(t_).n * H * W * ldx), 0,                   \
                                                 (int)((long)H * W * ldx * 2), 0x00020000);                            \
         wrs = __builtin_amdgcn_make_buffer_rsrc(umi_uniform_ptr(wp8 + (long)(t_).c0 * 8), 0,                          \
@@ -208,22 +224,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     do {                                                                                                              \
         int tid_ = threadIdx.x;                                                                                       \
         asm volatile("" : "+v"(tid_));                                                                                \
-        const int q = (tid_ >> 3) & 1, srow = ((tid_ >> 4) << 3) | (tid_ & 7);                                        \
+        const int hq = SC == 1 ? (tid_ >> 3) & 1 : (tid_ >> 3) & (C::NQ - 1);                                         \
+        const int hrow = SC == 1 ? ((tid_ >> 4) << 3) | (tid_ & 7) : ((tid_ >> 5) << 3) | (tid_ & 7);                 \
         _Pragma("unroll") for (int k = 0; k < C::KPH; ++k) {                                                          \
-            const int hp = srow + 128 * k;                                                                            \
+            const int hp = hrow + C::HPASS * k;                                                                       \
             if (hp < C::HALO_PIX && hoff[k] == OOB) {                                                                 \
                 unsigned z0 = 0;                                                                                      \
                 asm volatile("" : "+v"(z0));        /* made here: a zero vector kept in registers across the tile loop is a spill */ \
-                *reinterpret_cast<uint4*>(smem + hp * ROWB + q * 16) = make_uint4(z0, z0, z0, z0);                    \
+                *reinterpret_cast<uint4*>(smem + hp * HROWB + hq * 16) = make_uint4(z0, z0, z0, z0);                  \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
 
     half8 hraw[C::KPH], wraw[C::KPW];
-#define UMI_ISSUE(c_)                                                                                              \
+#define UMI_ISSUE_H(sc_)                                                                                          \
     do {                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < C::KPH; ++k)                                                        \
-            hraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[k], (c_) * 32, 0)); \
+            hraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(xrs, hoff[k], (sc_) * (32 * SC), 0)); \
+    } while (0)
+#define UMI_ISSUE_W(c_)                                                                                           \
+    do {                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < C::KPW; ++k)                                                        \
             wraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                            \
                 wrs, (C::W_LAST_PARTIAL && k == C::KPW - 1) ? wbase_l : wbase_v, (c_) * 2 * Co * 16 + k * wstep_s, 0)); \
@@ -233,22 +253,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     // juggling in the loop.  txbuf[c & 1] holds the rows of chunk c, txr those of chunk c + 2 (indices wrap: the surplus loads
     // of the last two chunks read rows that exist).
     const bool tx_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
-    const int txi = lane & 15;                                          // row of the chunk this thread carries
-    const int txs = (txi & 7) * 2 + (txi >> 3);                         // its slot, [j][q]: the two channel halves of a chunk
-                                                                        // side by side, so lanes q = 0 / 1 read different banks
+    const int txi = lane & (16 * SC - 1);                               // row of the super-chunk this thread carries
+    const int txs = (txi & 7) * C::NQ + (txi >> 3);                     // its slot, [j][q]: the channel groups of a chunk side
+                                                                        // by side, so lanes of different q read different banks
+    const int nsc = nchunks / SC;                                       // super-chunks (the launcher guarantees SC | nchunks)
     float4 txr = make_float4(0.f, 1.f, 0.f, 0.f);
     int txc = 0;                                                        // chunk whose rows txr holds
+    // (rows come through a descriptor: a 64-bit row pointer per lane kept across the loop is a register pair too many)
+    const __amdgpu_buffer_rsrc_t txrs = __builtin_amdgcn_make_buffer_rsrc(umi_uniform_ptr(tx), 0, HAS_TX ? Ci * 16 : 0, 0x00020000);
+#define UMI_TX_ROWS(sc_) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(txrs, txi * 16, (sc_) * (16 * SC * 16), 0))
 
     const Tile cur = decode(blockIdx.x);
     UMI_PLAN(cur);
-    UMI_ISSUE(0);                       // first: the prologue's one global round trip covers the transform rows as well
+    UMI_ISSUE_H(0);                     // first: the prologue's one global round trip covers the transform rows as well
+    UMI_ISSUE_W(0);
     UMI_ZERO_PADDING();
     if (HAS_TX) {
         if (tx_wave) {
-            txbuf[0][txs] = tx[txi];
-            txbuf[1][txs] = tx[(1 % nchunks) * 16 + txi];
-            txc = 2 % nchunks;
-            txr = tx[txc * 16 + txi];
+            txbuf[0][txs] = UMI_TX_ROWS(0);
+            txbuf[1][txs] = UMI_TX_ROWS(1 % nsc);
+            txc = 2 % nsc;
+            txr = UMI_TX_ROWS(txc);
         }
         __syncthreads();
     }
@@ -265,21 +290,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         if (n_chunks_done == 0) t_pro = t_loop - t_start;
 #endif
         for (int ci_ = 0; ci_ < nchunks; ++ci_) {
+            const int sci = ci_ / SC, sub = ci_ % SC;              // super-chunk, 16-channel chunk inside it
+            const bool first = SC == 1 || sub == 0;                // this iteration stages a halo tile
 #ifdef UMI_STAMP
             UMI_T(t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             UMI_T(t0b);
 #endif
             // ---- registers -> (transform) -> LDS ----------------------------------------------------
-            if (HAS_TX) {
-                float4 t[8];
+            if (first) {
+                if (HAS_TX) {
+                    float4 t[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = txbuf[ci_ & 1][j * 2 + q];
+                    for (int j = 0; j < 8; ++j) t[j] = txbuf[sci & 1][j * C::NQ + hq];
 #pragma unroll
-                for (int k = 0; k < C::KPH; ++k) hraw[k] = umi_tx8(hraw[k], t);
+                    for (int k = 0; k < C::KPH; ++k) hraw[k] = umi_tx8(hraw[k], t);
+                }
+#pragma unroll
+                for (int k = 0; k < C::KPH; ++k)
+                    *reinterpret_cast<half8*>(smem + (k == C::KPH - 1 ? hl_last : (hoff[k] != OOB ? hl_a : hl_b) + k * C::HPASS * HROWB)) = hraw[k];
             }
-#pragma unroll
-            for (int k = 0; k < C::KPH; ++k) *reinterpret_cast<half8*>(smem + hl[k]) = hraw[k];
 #pragma unroll
             for (int k = 0; k < C::KPW; ++k)
                 *reinterpret_cast<half8*>(smem + ((C::W_LAST_PARTIAL && k == C::KPW - 1) ? wl_last : wl_base + k * 128 * ROWB)) = wraw[k];
@@ -290,12 +320,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #ifdef UMI_STAMP
             UMI_T(t2);
 #endif
-            if (HAS_TX && tx_wave) {
-                txbuf[ci_ & 1][txs] = txr;            // every thread is past its reads of this buffer (barrier above)
-                txc = txc + 1 < nchunks ? txc + 1 : 0;
-                txr = tx[txc * 16 + txi];
+            if (first) {
+                if (HAS_TX && tx_wave) {
+                    txbuf[sci & 1][txs] = txr;          // every thread is past its reads of this buffer (barrier above)
+                    txc = txc + 1 < nsc ? txc + 1 : 0;
+                    txr = UMI_TX_ROWS(txc);
+                }
+                if (sci + 1 < nsc) UMI_ISSUE_H(sci + 1);   // SC = 2: in flight for two MFMA phases
             }
-            if (ci_ + 1 < nchunks) UMI_ISSUE(ci_ + 1);
+            if (ci_ + 1 < nchunks) UMI_ISSUE_W(ci_ + 1);
 
             // ---- MFMA phase: 9 taps x (2 x 4) tiles -----------------------------------------------
             // raised wave priority for the MFMA phase: when the two waves of a SIMD compete, the one feeding the matrix pipe wins
@@ -306,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                 half8 bf[6];
 #pragma unroll
                 for (int rr = 0; rr < 6; ++rr)
-                    bf[rr] = *reinterpret_cast<const half8*>(smem + b_base + (rr * HALO_W + dx) * ROWB);
+                    bf[rr] = *reinterpret_cast<const half8*>(smem + b_base + (rr * HALO_W + dx) * HROWB + sub * 32);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     half8 af[2];
@@ -511,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #endif
 }
 
-template <int TH, int BN>
+template <int TH, int BN, int SC>
 int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H, int W,
            int Ci, int Co, const BnRed* bnred, hipStream_t s, const void* out_tx = nullptr) {
     const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = (Co + BN - 1) / BN;
@@ -522,7 +555,7 @@ int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int
     const int xcd_chunk = (n_co > 1 && !xcd_off) ? (int)(nblk / 8) : 0;     // ids beyond 8 * chunk (the remainder) keep their order
     const BnRed bn = bnred ? *bnred : BnRed{nullptr, 0, (const float4*)out_tx, nullptr};
 #define GO(HT, EP)                                                                                               \
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, HT, EP>), grid, block, 0, s, (const half_t*)x, ldx, \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, SC, HT, EP>), grid, block, 0, s, (const half_t*)x, ldx, \
                        (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
                        tiles_y, n_co, xcd_chunk, bn)
     if (out_tx) { if (tx) GO(true, 3); else GO(false, 3); }
@@ -534,7 +567,9 @@ int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int
     return UMI_OK;
 }
 
-#undef UMI_ISSUE
+#undef UMI_ISSUE_H
+#undef UMI_TX_ROWS
+#undef UMI_ISSUE_W
 #undef UMI_PLAN
 #undef UMI_ZERO_PADDING
 }  // namespace
@@ -576,8 +611,9 @@ int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Ci, int Co, int ldx) {
 
 #define UMI_GO(...)                                                                          \
     do {                                                                                     \
-        if (use_bn128(Co)) return launch<8, 128>(__VA_ARGS__);                               \
-        return launch<16, 64>(__VA_ARGS__);                                                  \
+        if (use_bn128(Co)) return launch<8, 128, 1>(__VA_ARGS__);                            \
+        if (Ci % 32 == 0 && g_impl != 2) return launch<16, 64, 2>(__VA_ARGS__);              \
+        return launch<16, 64, 1>(__VA_ARGS__);                                               \
     } while (0)
 
 int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* stat_part,
