@@ -349,3 +349,60 @@ def test_transunet_submodules_run_standalone():
     assert tuple(y.shape) == (2, cfg.decoder_channels[-1], 64, 64)
     y.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in dec.parameters())
+
+
+@pytest.mark.gpu
+def test_block_applied_twice_in_one_tape_accumulates_both_gradients():
+    """A ViT Block (LayerNorm, Q/K/V/out/fc1/fc2 linears with biases) applied twice in ONE fp16 tape: the grouped
+    end-of-backward launches (umi_conv_wgrad_group, umi_colsum_group, umi_gn_param_grads_group) WRITE their outputs, so the
+    second use of every parameter has to be added after them.  Reference: torch autograd, CPU fp32."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    import copy
+    import torch.nn.functional as F
+    from Model import _run_tape
+    from umi.graph_tu import TUTape
+    from TransUnet import vit_seg_modeling as vsm
+    cfg = product_config(ref_transunet.small_config(2), 64)
+    cfg.transformer["dropout_rate"] = 0.0
+    hid, heads = cfg.hidden_size, cfg.transformer["num_heads"]
+    torch.manual_seed(7)
+    blk = vsm.Block(cfg, False)
+    for p in blk.parameters():                     # biases / LayerNorm weights away from their trivial initial values
+        if p.dim() == 1:
+            p.data += 0.1 * torch.randn_like(p)
+    ref = copy.deepcopy(blk).train()
+
+    def ref_block(m, x):
+        def attn(a, v):
+            B, N, C = v.shape
+            sp = lambda t: t.view(B, N, heads, C // heads).permute(0, 2, 1, 3)
+            p = torch.softmax(sp(a.query(v)) @ sp(a.key(v)).transpose(-1, -2) / (C // heads) ** 0.5, -1)
+            return a.out((p @ sp(a.value(v))).permute(0, 2, 1, 3).reshape(B, N, C))
+        h = x + attn(m.attn, F.layer_norm(x, (hid,), m.attention_norm.weight, m.attention_norm.bias, 1e-6))
+        return h + m.ffn.fc2(F.gelu(m.ffn.fc1(F.layer_norm(h, (hid,), m.ffn_norm.weight, m.ffn_norm.bias, 1e-6))))
+
+    class Twice(torch.nn.Module):
+        def __init__(self, b):
+            super().__init__()
+            self.b = b
+            self._compute_dtype = "fp16"
+
+        def forward(self, x):
+            build = lambda t, a: vsm._build_block(t, vsm._build_block(t, a, self.b), self.b)
+            return vsm._tok_out(_run_tape(self, [vsm._tok_in(x)], build, tape_cls=TUTape, dtype=torch.float16))
+
+    x = torch.randn(2, 16, hid)
+    gy = torch.randn(2, 16, hid)
+    m = Twice(blk.to(DEV)).train()
+    y = m(x.to(DEV))
+    y.backward(gy.to(DEV))
+    yr = ref_block(ref, ref_block(ref, x))
+    yr.backward(gy)
+    rel = lambda a, b: ((a.detach().float().cpu() - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(y, yr.detach()) < 2e-2
+    for (k, p), (_, rp) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, k
+        if k == "attn.key.bias":                   # softmax is invariant to a shift of the keys: this gradient is rounding noise
+            continue
+        assert rel(p.grad, rp.grad) < 6e-2, (k, rel(p.grad, rp.grad))      # a dropped second contribution is off by ~0.5-1

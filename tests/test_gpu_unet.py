@@ -830,3 +830,45 @@ def test_unet_ragged_sizes_match_oracle(shape):
     tiny = H * W <= 256
     assert max(errs.values()) < (1e-1 if tiny else 3e-2), max(errs.items(), key=lambda kv: kv[1])
     assert float(np.median(list(errs.values()))) < (6e-2 if tiny else 2e-3)
+
+
+# ---- a module applied twice in one tape (deferred gradient fills) ------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-3), ("fp16", 6e-2)])
+def test_module_used_twice_in_one_tape_accumulates_both_gradients(dtype, tol):
+    """The grouped end-of-backward launches WRITE their outputs; a second use of the same parameters must be added after
+    them, not onto the still unfilled buffer.  Reference: torch autograd on CPU (weights shared by two applications)."""
+    _need_gpu()
+    import Model
+    torch.manual_seed(5)
+    dc = Model.DoubleConv(16, 16, compute_dtype=dtype)
+    dc.load_state_dict(recipe.fill_state_dict(dc.state_dict(), seed=11))
+    ref = torch.nn.Module()                     # plain PyTorch restatement of Model.DoubleConv (same state_dict keys)
+    ref.double_conv = torch.nn.Sequential(
+        torch.nn.Conv2d(16, 16, 3, padding=1, bias=False), torch.nn.BatchNorm2d(16), torch.nn.ReLU(),
+        torch.nn.Conv2d(16, 16, 3, padding=1, bias=False), torch.nn.BatchNorm2d(16), torch.nn.ReLU())
+    ref.load_state_dict(dc.state_dict())
+    ref.forward = lambda v: ref.double_conv(v)
+    dc = dc.to(DEV)
+
+    class Twice(Model._UmiModule):
+        def __init__(self, block):
+            super().__init__()
+            self.block = block
+            self._compute_dtype = dtype
+
+        def forward(self, x):
+            return Model._run_tape(self, [x], lambda t, a: Model._build_double_conv(
+                t, Model._build_double_conv(t, a, self.block), self.block))
+
+    x = torch.randn(2, 16, 24, 40)
+    gy = torch.randn(2, 16, 24, 40)
+    m = Twice(dc).train()
+    y = m(x.to(DEV))
+    y.backward(gy.to(DEV))
+    ref.train()
+    yr = ref(ref(x))
+    yr.backward(gy)
+    assert max_err_scaled(y, yr) < tol
+    got = dict(dc.named_parameters())
+    for name, p in ref.named_parameters():
+        assert rel_err(got[name].grad, p.grad) < tol, name

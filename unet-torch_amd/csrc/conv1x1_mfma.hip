@@ -395,6 +395,9 @@ int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, co
         M = (long)N * Ho * Wo;
         ntaps = R * S;
     }
+    // the gather / scatter modes address a source image with 31-bit byte offsets relative to the tile's first image (two
+    // images in reach): refuse what does not fit instead of wrapping (~1 GB per image, no shipped config)
+    if (mode != 0 && 2L * H * W * ldx * 2 >= 0x7FFFFFF0L) return UMI_ERR_UNSUPPORTED;
     // largest tile that still gives every CU two workgroups; small GEMMs (ViT linears: 4,704 tokens x 768) take
     // 128-pixel tiles, and 64-channel ones if that is still not enough
     const bool bn128 = Ntot % 128 == 0;

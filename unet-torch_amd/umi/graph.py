@@ -78,7 +78,12 @@ class Tape:
         self.param_grads = {}             # id(param) -> (param, grad tensor)
         self._deferred_unscale = []       # BatchNorm parameter gradients still carrying the loss scale
         self._nbt = []
-        self._wgrad_deferred = None                    # num_batches_tracked counters of the BatchNorm layers run in training mode
+        self._wgrad_deferred = None
+        # Deferred fills: a gradient buffer registered in param_grads whose CONTENT is only written (with `=`) by a grouped
+        # launch at the end of the backward pass.  A later contribution to the same parameter (a module used twice in one
+        # tape) must not be add_()-ed onto the still unfilled buffer: it is parked and added after the flush.
+        self._pending_fill = []           # [lo, hi) address ranges of such buffers (gradients may be views into them)
+        self._late_adds = []              # (destination, addend) pairs applied after every deferred fill has run
         self._inputs = []
 
     # ---- helpers -----------------------------------------------------------------------
@@ -93,6 +98,21 @@ class Tape:
             return c.get(kind, weight, self.dtype, k8)
         return ops.PACKERS[kind](wf, self.dtype, k8=k8)
 
+    def _defer_list(self, weight, gw):
+        """The list a weight gradient's split-K reduction is deferred to (and `gw` marked as filled at the flush), or None."""
+        if self._wgrad_deferred is None:
+            return None
+        self._mark_deferred_fill(gw)
+        return self._wgrad_deferred
+
+    def _mark_deferred_fill(self, *bufs):
+        for b in bufs:
+            self._pending_fill.append((b.data_ptr(), b.data_ptr() + b.numel() * b.element_size()))
+
+    def _is_pending_fill(self, t):
+        a = t.data_ptr()
+        return any(lo <= a < hi for lo, hi in self._pending_fill)
+
     def _new_pgrad(self, p):
         """fp32 tensor the wgrad kernel writes into: a slot of the reducer's flat bucket when present."""
         v = self.grad_sink.buffer_for(p) if self.grad_sink is not None else None
@@ -101,7 +121,14 @@ class Tape:
     def _set_pgrad(self, p, g):
         key = id(p)
         if key in self.param_grads:
-            self.param_grads[key][1].add_(g)
+            dst = self.param_grads[key][1]
+            if self.grad_sink is not None and self.grad_sink.buffer_for(p) is not None:
+                # its bucket may already be on the wire (mark_ready at the first use)
+                raise NotImplementedError("a parameter used twice in one tape under a gradient sink (umi.ddp.GradReducer)")
+            if self._is_pending_fill(dst) or self._is_pending_fill(g):
+                self._late_adds.append((dst, g))
+            else:
+                dst.add_(g)
             return
         v = self.grad_sink.buffer_for(p) if self.grad_sink is not None else None
         if v is not None:
@@ -252,7 +279,7 @@ class Tape:
                         ops.bn_bwd_apply(o.grad, out, tx, rstd, dbeta, dgamma)
                 if not fuse:
                     ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad,
-                                   defer=self._wgrad_deferred if id(weight) not in self.param_grads else None)
+                                   defer=self._defer_list(weight, gw))
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
@@ -301,7 +328,7 @@ class Tape:
                 g = o.grad
                 gw = self._new_pgrad(weight)
                 ops.conv_wgrad(a.raw, a.tx, g, None, gw, Ci * R * S, R * S, 1, inv, R, S, 1, pad,
-                               defer=self._wgrad_deferred if id(weight) not in self.param_grads else None)
+                               defer=self._defer_list(weight, gw))
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
@@ -384,8 +411,7 @@ class Tape:
                     self._set_pgrad(bias, gb)
                 gw = self._new_pgrad(weight)
                 # dW[ci][co][t] = sum_p act(a)[p][ci] * g[2p+t][co]: a wgrad with the roles of x and dy swapped
-                ops.conv_wgrad(g, None, a.raw, a.tx, gw, Cout * 4, 4, 1, inv, 2, 2, 2, 0,
-                               defer=self._wgrad_deferred if id(weight) not in self.param_grads else None)
+                ops.conv_wgrad(g, None, a.raw, a.tx, gw, Cout * 4, 4, 1, inv, 2, 2, 2, 0, defer=self._defer_list(weight, gw))
                 self._set_pgrad(weight, gw)
                 if _wants_grad(a):
                     tgt = self._accumulate_target(a, g, 2, 2, 2, 0)
@@ -513,6 +539,9 @@ class Tape:
             ops.wgrad_reduce_flush(self._wgrad_deferred)     # the split-K reductions of all layers, 16 per launch
         self._wgrad_deferred = None
         self._finish_param_grads()
+        for dst, src in self._late_adds:                    # second uses of a parameter whose first gradient was a deferred fill
+            dst.add_(src)
+        self._late_adds, self._pending_fill = [], []
         if self._deferred_unscale:
             torch._foreach_mul_(self._deferred_unscale, self.inv)
             self._deferred_unscale = []

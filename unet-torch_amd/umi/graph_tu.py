@@ -52,12 +52,12 @@ class TUTape(Tape):
     # only 4,704 rows to reduce over and 36-144 output tiles: filling 256 CUs took a 7-9-way split-K whose slabs cost more
     # than the GEMM.  288 GB of HBM keep the ~0.8 GB of operands alive until then.
     def _defer_wgrad(self, weight, x, tx, dy, gw, s_co, s_ci):
-        if (tx is not None or self.grad_sink is not None or self.dtype != torch.float16 or id(weight) in self.param_grads
-                or _no_wgrad_group()):
+        if tx is not None or self.grad_sink is not None or self.dtype != torch.float16 or _no_wgrad_group():
             return False
         key = (tuple(x.shape), x.stride(), tuple(dy.shape), dy.stride(), s_co, s_ci)
         self._wgrad_groups.setdefault(key, []).append((x, dy, gw))
         self._readonly.add(dy.data_ptr())
+        self._mark_deferred_fill(gw)            # a module used twice: Tape._set_pgrad parks the second gradient until the flush
         return True
 
     def _defer_colsum(self, dy, gb):
@@ -65,6 +65,7 @@ class TUTape(Tape):
         if dy.data_ptr() not in self._readonly:
             return False
         self._colsum_groups.setdefault((tuple(dy.shape), dy.stride()), []).append((dy, gb))
+        self._mark_deferred_fill(gb)
         return True
 
     def _flush_wgrad_groups(self):
@@ -115,6 +116,8 @@ class TUTape(Tape):
                 gws = slot[0] if slot is not None else torch.empty_like(ws)
                 ops.conv_wgrad(a.raw, a.tx, o.grad, None, gws, Ci * R * S, R * S, 1, self.inv, R, S, stride, pad,
                                defer=self._wgrad_deferred if slot is not None else None)
+                if slot is not None:
+                    self._mark_deferred_fill(slot[1])
                 # with a slot the standardisation's backward runs once for all convs at the end of the backward pass
                 self._set_pgrad(w, slot[1] if slot is not None else ops_tu.wstd_bwd(ws, rstd, gws))
                 if _wants_grad(a):
@@ -130,7 +133,8 @@ class TUTape(Tape):
     def _wstd_slot(self, ent, w):
         """(gradient w.r.t. the standardised weight, parameter gradient) views of this conv in two flat per-step buffers; the
         second is filled by ONE umi_wstd_bwd_multi launch when the backward pass ends.  None where that deferral is not safe:
-        a gradient sink wants its own buffers filled as the pass proceeds, and a weight used twice accumulates at once."""
+        a gradient sink wants its own buffers filled as the pass proceeds, and a conv used twice has ONE slot (its second
+        gradient is computed at once and added after the flush, Tape._set_pgrad)."""
         if self.grad_sink is not None or id(w) in self.param_grads or any(e is ent for e in self._wstd_pending):
             return None
         if self._wstd_flat is None:
@@ -196,6 +200,7 @@ class TUTape(Tape):
                     dg, db = torch.empty(C, dtype=torch.float32, device=out.device), torch.empty(C, dtype=torch.float32,
                                                                                                   device=out.device)
                     self._gn_pending.append((part, N, dg, db))
+                    self._mark_deferred_fill(dg, db)
                 else:
                     dg, db = ops_tu.gn_bwd(o.grad, out, a.raw, mean, rstd, g32, gn.num_groups, relu, dx, dres, self.inv)
                 self._set_pgrad(gn.weight, dg)
@@ -261,7 +266,7 @@ class TUTape(Tape):
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
-                    if id(bias) in self.param_grads or not self._defer_colsum(o.grad, gb):
+                    if not self._defer_colsum(o.grad, gb):
                         ops.colsum(o.grad, gb, self.inv)
                     self._set_pgrad(bias, gb)
                 if _wants_grad(a):
@@ -292,6 +297,7 @@ class TUTape(Tape):
                     dg, db = torch.empty(C, dtype=torch.float32, device=out.device), torch.empty(C, dtype=torch.float32,
                                                                                                   device=out.device)
                     self._gn_pending.append((part, rows, dg, db))        # summed with the GroupNorm rows at the end of the pass
+                    self._mark_deferred_fill(dg, db)
                 else:
                     dg, db = ops_tu.ln_bwd(o.grad, a.raw, g32, mean, rstd, dx, self.inv)
                 self._set_pgrad(ln.weight, dg)
@@ -373,7 +379,8 @@ class TUTape(Tape):
                     return
                 dx = torch.empty_like(a.raw)
                 if gelu:
-                    assert ops_tu.dropout_fused(o.grad, dx, mask, True, p, 0, None, a.raw, True)
+                    if not ops_tu.dropout_fused(o.grad, dx, mask, True, p, 0, None, a.raw, True):     # never inside an assert:
+                        raise RuntimeError("umi_dropout_fused refused the GELU + dropout backward")   # `python -O` drops those
                 else:
                     ops_tu.dropout(o.grad, dx, mask, True, p, 0)
                 if add is not None:                    # the residual branch receives the same tensor (read-only, see add())
@@ -435,11 +442,10 @@ class TUTape(Tape):
                 dqkv = self.alloc(N, H, W, 3 * C, device=out.device)
                 ops_tu.attn_bwd(q, k, v, out, o.grad, lse, *(dqkv[..., i * C:(i + 1) * C] for i in range(3)), heads)
                 gw = torch.empty(3 * C, C, dtype=torch.float32, device=out.device)
-                if any(id(m.weight) in self.param_grads for m in mods) or not self._defer_wgrad(query.weight, a.raw, a.tx, dqkv,
-                                                                                                 gw, C, 1):
+                if not self._defer_wgrad(query.weight, a.raw, a.tx, dqkv, gw, C, 1):
                     ops.conv_wgrad(a.raw, a.tx, dqkv, None, gw, C, 1, 1, self.inv, 1, 1, 1, 0)
                 gb = torch.empty(3 * C, dtype=torch.float32, device=out.device)
-                if any(id(m.bias) in self.param_grads for m in mods) or not self._defer_colsum(dqkv, gb):
+                if not self._defer_colsum(dqkv, gb):
                     ops.colsum(dqkv, gb, self.inv)
                 for i, m in enumerate(mods):
                     self._set_pgrad(m.weight, gw[i * C:(i + 1) * C])

@@ -35,6 +35,7 @@ class _Table:
     def __init__(self):
         self.key, self.dev, self.blocks, self.n = None, None, 0, 0
         self.host, self.events, self.turn = [None, None], [None, None], 0
+        self.captured = set()                            # staging buffers a captured graph replays from
 
     def _ensure(self, nbytes):
         if self.dev is None or self.dev.numel() < nbytes:
@@ -59,6 +60,14 @@ class _Table:
             self._ensure(raw.size)
             capturing = torch.cuda.is_current_stream_capturing()
             self.turn ^= 1                               # two staging buffers: the previous upload may still be in flight
+            if capturing:
+                # a captured upload node re-reads ITS staging buffer at every replay: a third capture (a third batch shape)
+                # would overwrite the buffer the first graph still replays from, and that graph would step the parameters
+                # with another graph's gradient addresses.  Trainer(graph=True) captures two shapes (full and ragged batch).
+                if self.turn in self.captured:
+                    raise RuntimeError("umi.optim: more than two HIP-graph captures share this optimizer's descriptor table "
+                                       "(two staging buffers); use one optimizer per set of captured shapes")
+                self.captured.add(self.turn)
             ev = self.events[self.turn]
             if ev is not None and not capturing:
                 ev.synchronize()
@@ -149,6 +158,20 @@ class _DeviceHyper:
     def state_dict(self):
         self.sync_host()
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Loading a state dict rewrites param_groups[i]['lr'] and Adam's step counts on the host; with a device schedule active
+        the device block is what step() reads, so it is rebuilt from the loaded values (the poly rule keeps its base_lr /
+        max_iterations / power and the ITERATION COUNT of the block: pass iter_num to device_schedule() to resume elsewhere)."""
+        blocks = self.sync_host() if self.device_hyper is not None else []
+        super().load_state_dict(state_dict)
+        if self.device_hyper is not None:
+            poly = None
+            if self._umi_poly and blocks:
+                h = blocks[0]
+                poly = dict(base_lr=float(h["base_lr"]), max_iterations=float(h["max_iter"]), power=float(h["power"]),
+                            iter_num=float(h["iter"]))
+            self.device_schedule(poly=poly)
 
 
 def _check(p):
