@@ -70,7 +70,7 @@ def test_product_transunet_surface_and_init(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,ncls", [("transunet_small", 2), ("transunet_small_rgb4", 4)])
+@pytest.mark.parametrize("name,ncls", [("transunet_small", 2), ("transunet_small_rgb4", 4), ("transunet_small_neg_gamma", 2)])
 def test_transunet_small_fp32_parity(golden_dir, name, ncls):
     if not torch.cuda.is_available():
         pytest.fail("needs an MI355X")
@@ -80,7 +80,8 @@ def test_transunet_small_fp32_parity(golden_dir, name, ncls):
     cfg = ref_transunet.small_config(ncls)
     img, B, cin, seed = int(g["img"]), int(g["B"]), int(g["cin"]), int(g["seed"])
     ref = ref_transunet.RefTransUNet(cfg, img)
-    ref.load_state_dict(recipe.fill_state_dict(ref.state_dict(), seed=seed, negative_gamma=False))
+    neg = bool(int(g["neg_gamma"])) if "neg_gamma" in g else False      # every 7th norm scale negative (oracle/recipe.py)
+    ref.load_state_dict(recipe.fill_state_dict(ref.state_dict(), seed=seed, negative_gamma=neg))
     x, lab = recipe.synthetic_batch(B, cin, img, img, ncls, seed=seed)
     L.CLASS_NUMBER = ncls
     m = VisionTransformer(product_config(cfg, img), img_size=img, num_classes=ncls, compute_dtype="fp32")
@@ -114,8 +115,11 @@ def test_transunet_small_fp32_parity(golden_dir, name, ncls):
 
 
 @pytest.mark.gpu
-def test_transunet_r50_vit_b16_224_fp32(golden_dir):
-    """Full R50-ViT-B/16 @224 (config 4 shape, B=1): logits signature, loss and per-parameter grad norms vs the reference."""
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_transunet_r50_vit_b16_224(golden_dir, dtype):
+    """Full R50-ViT-B/16 @224 (BASELINE configs[3] shape, B=1: 196 tokens, the 55 -> 56 skip pad): logits signature, loss and
+    per-parameter grad norms vs the reference.  fp16 storage (the matrix-core kernels): sampled logits within 6e-2 of scale
+    (3e-2 at 512 x 512), loss within 5e-3, gradient norms of the large tensors within 25 %."""
     if not torch.cuda.is_available():
         pytest.fail("needs an MI355X")
     import loss as L
@@ -123,7 +127,7 @@ def test_transunet_r50_vit_b16_224_fp32(golden_dir):
     g = np.load(os.path.join(golden_dir, "transunet_r50_b16_224.npz"))
     cfg = ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)
     L.CLASS_NUMBER = 2
-    m = VisionTransformer(product_config(cfg, 224), img_size=224, num_classes=2, compute_dtype="fp32")
+    m = VisionTransformer(product_config(cfg, 224), img_size=224, num_classes=2, compute_dtype=dtype)
     assert len(m.state_dict()) == 409
     m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=int(g["seed"]), negative_gamma=False))
     m.to(DEV).train()
@@ -132,15 +136,25 @@ def test_transunet_r50_vit_b16_224_fp32(golden_dir):
     loss = L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc")
     loss.backward()
     s = sig(logits.cpu())
-    np.testing.assert_allclose(s[[0, 2]], g["logits_sig"][[0, 2]], rtol=2e-4)
-    np.testing.assert_allclose(s[3:], g["logits_sig"][3:], rtol=1e-3, atol=1e-3 * s[0] / 300)
-    assert abs(loss.item() - float(g["loss0"])) < 2e-5
+    if dtype == "fp32":
+        np.testing.assert_allclose(s[[0, 2]], g["logits_sig"][[0, 2]], rtol=2e-4)
+        np.testing.assert_allclose(s[3:], g["logits_sig"][3:], rtol=1e-3, atol=1e-3 * s[0] / 300)
+        assert abs(loss.item() - float(g["loss0"])) < 2e-5
+    else:
+        scale = np.abs(g["logits_sig"][3:]).max()
+        np.testing.assert_allclose(s[[0, 2]], g["logits_sig"][[0, 2]], rtol=2e-2)
+        # 16 sampled logits: measured 4.6e-2 of the sampled scale here against < 3e-2 at 512 x 512 (B = 1: the decoder's
+        # BatchNorm statistics and the 14 x 14 token grid average fp16 rounding over ~5x fewer values than at 512 x 512)
+        assert np.abs(s[3:] - g["logits_sig"][3:]).max() < 6e-2 * max(scale, s[0] / 300)
+        assert abs(loss.item() - float(g["loss0"])) < 5e-3
     bad = []
     for k, p in m.named_parameters():
         ref_norm = float(g["grad_sig." + k][0])
-        if ref_norm < 1e-7:              # e.g. key biases: mathematically zero gradient, pure rounding noise
+        assert torch.isfinite(p.grad).all(), k
+        if ref_norm < 1e-7 or (dtype == "fp16" and p.numel() < 4096):   # e.g. key biases: mathematically zero gradient
             continue
-        if abs(p.grad.double().norm().item() - ref_norm) > 1e-2 * ref_norm:
+        tol = 1e-2 if dtype == "fp32" else 0.25
+        if abs(p.grad.double().norm().item() - ref_norm) > tol * ref_norm:
             bad.append((k, p.grad.double().norm().item(), ref_norm))
     assert not bad, bad[:5]
 

@@ -11,6 +11,7 @@ from tests.test_oracle_golden import _sig_close, sig
 CASES = {
     "transunet_small": (lambda: ref_transunet.small_config(2)),
     "transunet_small_rgb4": (lambda: ref_transunet.small_config(4)),
+    "transunet_small_neg_gamma": (lambda: ref_transunet.small_config(2)),     # every 7th norm scale negative
     "transunet_r50_b16_224": (lambda: ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)),
     # BASELINE configs[4] shape: 1,024 tokens, 127 -> 128 zero-pad of the 1/4-scale ResNet skip (resnet_skip.py:147-158)
     "transunet_r50_b16_512": (lambda: ref_transunet.r50_vit_b16_config(2, 3, dropout_rate=0.0)),
@@ -27,7 +28,7 @@ def test_transunet_oracle_matches_reference(golden_dir, name):
     sd = m.state_dict()
     assert len(sd) == int(g["n_keys"])
     assert sorted(sd.keys()) == sorted(g["keys"].tolist())          # identical key set as the reference
-    m.load_state_dict(recipe.fill_state_dict(sd, seed=seed, negative_gamma=False))
+    m.load_state_dict(recipe.fill_state_dict(sd, seed=seed, negative_gamma=bool(int(g["neg_gamma"])) if "neg_gamma" in g else False))
     x, lab = recipe.synthetic_batch(B, cin, img, img, cfg["n_classes"], seed=seed)
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     m.train()

@@ -350,12 +350,17 @@ def main():
     ap.add_argument("--big", action="store_true", help="also config-1 scale UNet(1,2,64) 256^2")
     ap.add_argument("--load-from", action="store_true", help="only the TransUNet load_from fixture")
     ap.add_argument("--tu512", action="store_true", help="only the R50-ViT-B/16 @512 TransUNet fixture (BASELINE configs[4] shape)")
+    ap.add_argument("--tu-neg-gamma", action="store_true", help="only the small TransUNet fixture with negative norm scales")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     Model, loss_mod, Trainer = import_reference()
     if a.load_from:
         from tools import gen_golden_transunet
         gen_golden_transunet.run(import_reference, sig, meta, GOLD, only_load_from=True)
+        return
+    if a.tu_neg_gamma:
+        from tools import gen_golden_transunet
+        gen_golden_transunet.run(import_reference, sig, meta, GOLD, only_neg=True)
         return
     if a.tu512:
         from tools import gen_golden_transunet

@@ -26,15 +26,15 @@ def _ref_config(cfg, img_size):
     return c
 
 
-def _case(vsm, loss_mod, sig, meta, GOLD, name, cfg, img, B, cin, seed, full):
+def _case(vsm, loss_mod, sig, meta, GOLD, name, cfg, img, B, cin, seed, full, neg_gamma=False):
     torch.manual_seed(0)
     loss_mod.CLASS_NUMBER = cfg["n_classes"]
     m = vsm.VisionTransformer(_ref_config(cfg, img), img_size=img, num_classes=cfg["n_classes"])
-    out = dict(img=img, B=B, cin=cin, seed=seed, n_keys=len(m.state_dict()))
+    out = dict(img=img, B=B, cin=cin, seed=seed, n_keys=len(m.state_dict()), neg_gamma=int(neg_gamma))
     out["keys"] = np.array(list(m.state_dict().keys()))
     for k, v in m.state_dict().items():                # the reference's own init under torch.manual_seed(0)
         out["init_sig." + k] = sig(v.float())
-    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed, negative_gamma=False))
+    m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=seed, negative_gamma=neg_gamma))
     x, lab = recipe.synthetic_batch(B, cin, img, img, cfg["n_classes"], seed=seed)
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     m.train()
@@ -110,11 +110,17 @@ def _case_load_from(vsm, sig, meta, GOLD):
     print("wrote transunet_small_load_from.npz", out["zoom.n_ckpt_keys"], len(out["zoom.changed"]))
 
 
-def run(import_reference, sig, meta, GOLD, big=False, only512=False, only_load_from=False):
+def run(import_reference, sig, meta, GOLD, big=False, only512=False, only_load_from=False, only_neg=False):
     _, loss_mod, _ = import_reference()
     from TransUnet import vit_seg_modeling as vsm
     if only_load_from:
         _case_load_from(vsm, sig, meta, GOLD)
+        return
+    if only_neg:
+        # every 7th GroupNorm / LayerNorm / BatchNorm scale negative (oracle/recipe.py): a fusion that assumes gamma > 0
+        # (e.g. a ReLU or max taken before the affine) shows up here; VERDICT round 2, "TransUNet fixtures use positive gammas"
+        _case(vsm, loss_mod, sig, meta, GOLD, "transunet_small_neg_gamma", ref_transunet.small_config(2), 64, 2, 1, 41, True,
+              neg_gamma=True)
         return
     if only512:
         # BASELINE configs[4] shape: R50-ViT-B/16 at 512 x 512 (1,024 tokens; the ResNet's 127 -> 128 zero-pad fix-up of the
