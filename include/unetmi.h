@@ -212,7 +212,8 @@ int umi_wstd_fwd(const float* w, float* wstd, float* rstd, int Co, int K, float 
 int umi_wstd_bwd(const float* wstd, const float* rstd, const float* g, float* dw, int Co, int K, umi_stream_t stream);
 /* The same for ALL StdConv2d layers of a model in one launch each way (a R50 hybrid has 52).  `descs`: DEVICE array sorted
  * by blk0; an entry owns Co workgroups.  Backward: the gradient w.r.t. the standardised weights of entry i is read at
- * g_base + off, the parameter gradient written at dw_base + off (flat per-step buffers, so the table never changes). */
+ * g_base + off, the parameter gradient written at dw_base + off (flat per-step buffers, so the table never changes) or,
+ * where the entry's `dw` is not NULL, there (e.g. the parameter's slot in a data-parallel gradient bucket). */
 typedef struct umi_wstd_desc {
     const float* w;
     float* ws;
@@ -221,6 +222,7 @@ typedef struct umi_wstd_desc {
     int Co, K;
     float eps;
     int blk0;
+    float* dw;
 } umi_wstd_desc;
 int umi_wstd_fwd_multi(const void* descs, int n_desc, int total_rows, umi_stream_t stream);
 int umi_wstd_bwd_multi(const void* descs, int n_desc, int total_rows, const float* g_base, float* dw_base, umi_stream_t stream);

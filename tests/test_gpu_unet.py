@@ -327,6 +327,34 @@ def test_grad_reducer_sink_path_matches_plain_backward():
         assert torch.equal(red.buffer_for(p), g)
 
 
+def test_grad_reducer_sink_path_matches_plain_backward_transunet():
+    """The same for the TransUNet tape: its grouped end-of-backward launches (token-linear weight
+    gradients per shape, bias column sums, GroupNorm / LayerNorm parameter gradients, the StdConv2d standardisation backward)
+    stay enabled under a sink and write straight into the bucket slots; .grad IS the slot (no autograd copy).  Launch counts
+    of the full R50-ViT-B/16 with and without the sink: tools/check_tu_sink.py (770 vs 795 per step)."""
+    _need_gpu()
+    from oracle import ref_transunet
+    from tests.test_gpu_transunet import product_config
+    from TransUnet.vit_seg_modeling import VisionTransformer
+    from umi import ddp
+    torch.manual_seed(3)
+    cfg = ref_transunet.small_config(2)
+    m = VisionTransformer(product_config(cfg, 64), img_size=64, num_classes=2, compute_dtype="fp16").to(DEV).train()
+    x = torch.randn(2, 1, 64, 64, device=DEV)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m(x).square().mean().backward()
+    plain = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    m.load_state_dict(sd)
+    red = ddp.GradReducer(m, world_size=1, bucket_mb=0.5)
+    assert len(red.buckets) > 1
+    m(x).square().mean().backward()
+    red.sync()
+    for (k, p), g in zip(m.named_parameters(), plain):
+        assert p.grad.data_ptr() == red.buffer_for(p).data_ptr(), k
+        assert torch.equal(p.grad, g), k
+
+
 def test_fused_dgrad_bn_reduction_matches_separate_kernels(monkeypatch):
     """DoubleConv's second conv: its data-gradient kernel also produces stage 1 of the first layer's BatchNorm backward
     reduction (umi_conv_dgrad_bnred).  Gradients must agree with the separate-kernel path (same values, other sum order)."""

@@ -57,9 +57,24 @@ class _TapeFunction(torch.autograd.Function):
         gin = [tape.input_grad_nchw(a) if need else None
                for a, need in zip(ctx.in_acts, ctx.needs_input_grad[3:3 + ctx.n_inputs])]
         gpar = []
+        sink = tape.grad_sink
         for p, need in zip(ctx.params, ctx.needs_input_grad[3 + ctx.n_inputs:]):
             g = tape.param_grads.get(id(p))
-            gpar.append(g[1].to(p.dtype) if (g is not None and need) else None)
+            if g is None or not need:
+                gpar.append(None)
+                continue
+            slot = sink.buffer_for(p) if sink is not None else None
+            if (slot is not None and g[1].data_ptr() == slot.data_ptr() and p.dtype == torch.float32
+                    and (p.grad is None or p.grad.data_ptr() == slot.data_ptr())):
+                # Data-parallel runs: the gradient already sits in its bucket slot and the optimizer reads it there.  Handing a
+                # VIEW of the bucket to autograd would make AccumulateGrad clone it -- one copy launch per parameter and step
+                # (409 for a R50-ViT-B/16) of values that GradReducer.sync() then discards.  .grad becomes the slot itself
+                # (semantics of zero_grad + backward; accumulating several backward passes into one step is not supported
+                # under a gradient sink).
+                p.grad = slot
+                gpar.append(None)
+            else:
+                gpar.append(g[1].to(p.dtype))
         ctx.tape = None
         return (None, None, None, *gin, *gpar)
 

@@ -358,6 +358,9 @@ class VisionTransformer(nn.Module):
             h, skips = _build_embeddings(tape, a, emb)
             gh = gw = int(np.sqrt(h.shape[2]))
             assert gh * gw == h.shape[2]
+            # data-parallel runs: when the backward pass comes back to this point the encoder's and decoders' deferred gradient
+            # fills run and their buckets go on the wire, under the hybrid ResNet's backward pass (a no-op without a sink)
+            tape.flush_mark()
             for blk in self.transformer.encoder.layer:
                 h = _build_block(tape, h, blk, cfg)
             h = tape.layer_norm(h, self.transformer.encoder.encoder_norm)

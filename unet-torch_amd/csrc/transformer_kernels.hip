@@ -76,6 +76,7 @@ struct WstdDesc {          // mirrors umi_wstd_desc
     int Co, K;
     float eps;
     int blk0;              // first workgroup (= output-channel row) of this conv
+    float* dw;             // backward: where this conv's parameter gradient goes (NULL: dw_base + off)
 };
 
 __device__ inline int wstd_find(const WstdDesc* d, int n, int blk) {
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void wstd_bwd_multi_kernel(const WstdDesc* __r
     const int co = blockIdx.x - d.blk0, K = d.K;
     const float* wh = d.ws + (long)co * K;
     const float* gp = g_base + d.off + (long)co * K;
-    float* dw = dw_base + d.off + (long)co * K;
+    float* dw = (d.dw ? d.dw : dw_base + d.off) + (long)co * K;
     float s = 0.f, q = 0.f;
     for (int i = threadIdx.x; i < K; i += 256) { float gv = gp[i]; s += gv; q = fmaf(gv, wh[i], q); }
     block_sum2(s, q, sh);
@@ -654,7 +655,7 @@ extern "C" int umi_wstd_fwd_multi(const void* descs, int n_desc, int total_rows,
 }
 extern "C" int umi_wstd_bwd_multi(const void* descs, int n_desc, int total_rows, const float* g_base, float* dw_base,
                                   umi_stream_t st) {
-    if (!descs || !g_base || !dw_base || n_desc <= 0 || total_rows <= 0) return UMI_ERR_BADARG;
+    if (!descs || !g_base || n_desc <= 0 || total_rows <= 0) return UMI_ERR_BADARG;      // dw_base may be NULL if every entry has .dw
     hipLaunchKernelGGL(wstd_bwd_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)st, (const WstdDesc*)descs, n_desc,
                        g_base, dw_base);
     UMI_LAUNCH_CHECK();

@@ -84,6 +84,7 @@ class Tape:
         # tape) must not be add_()-ed onto the still unfilled buffer: it is parked and added after the flush.
         self._pending_fill = []           # [lo, hi) address ranges of such buffers (gradients may be views into them)
         self._late_adds = []              # (destination, addend) pairs applied after every deferred fill has run
+        self._late_ready = []             # parameters whose bucket slot (gradient sink) is a deferred fill: mark_ready after it
         self._inputs = []
 
     # ---- helpers -----------------------------------------------------------------------
@@ -131,13 +132,30 @@ class Tape:
                 dst.add_(g)
             return
         v = self.grad_sink.buffer_for(p) if self.grad_sink is not None else None
+        late = False
         if v is not None:
+            late = self._is_pending_fill(g)
             if v.data_ptr() != g.data_ptr():
+                if late:
+                    raise RuntimeError("deferred gradient fills must target the sink's bucket slot (Tape._new_pgrad)")
                 v.copy_(g)
             g = v
         self.param_grads[key] = (p, g)
         if v is not None:
-            self.grad_sink.mark_ready(p)
+            if late:
+                self._late_ready.append(p)          # the slot is written by a grouped launch: ready once that has been issued
+            else:
+                self.grad_sink.mark_ready(p)
+
+    def _set_pgrad_scaled(self, p, g, scale):
+        """_set_pgrad(p, g * scale) with the product written straight into the sink's bucket slot when there is one (one
+        launch instead of a multiply and a copy)."""
+        v = self.grad_sink.buffer_for(p) if self.grad_sink is not None else None
+        if v is not None and id(p) not in self.param_grads and v.shape == g.shape:
+            torch.mul(g, scale, out=v)
+            self._set_pgrad(p, v)
+        else:
+            self._set_pgrad(p, g * scale)
 
     def _give(self, act: Act, g):
         """Route gradient `g` (NHWC view) to `act`; concat acts forward slices to their parts."""
@@ -266,8 +284,8 @@ class Tape:
                     self._set_pgrad(bn.weight, dgamma)
                     self._set_pgrad(bn.bias, dbeta)
                 else:
-                    self._set_pgrad(bn.weight, dgamma * inv)
-                    self._set_pgrad(bn.bias, dbeta * inv)
+                    self._set_pgrad_scaled(bn.weight, dgamma, inv)
+                    self._set_pgrad_scaled(bn.bias, dbeta, inv)
                 gw = self._new_pgrad(weight)
                 if fuse:
                     dz = self.alloc(N, Ho, Wo, Co, device=out.device)
@@ -530,18 +548,31 @@ class Tape:
         a.grad = torch.empty((N, H, W, C), dtype=self.dtype, device=g_nchw.device)
         a.grad.copy_(g)
 
-    def backward(self):
-        self._wgrad_deferred = [] if (self.grad_sink is None and _defer_wgrad_reduce()) else None
-        for step in reversed(self.steps):
-            step()
-        self.steps = []
+    # Deferred gradient fills under a gradient sink: the U-Net tape turns them off (every weight gradient goes to its bucket
+    # slot as the pass proceeds, the bucket's all-reduce overlaps the rest of the backward pass); TUTape keeps them and flushes
+    # at marked points (flush_mark), so whole groups of layers still cost one launch.
+    _defer_under_sink = False
+
+    def _flush_deferred(self):
+        """Run every deferred fill recorded so far, then the parked second contributions, then hand the filled bucket slots
+        to the gradient sink."""
         if self._wgrad_deferred:
             ops.wgrad_reduce_flush(self._wgrad_deferred)     # the split-K reductions of all layers, 16 per launch
-        self._wgrad_deferred = None
         self._finish_param_grads()
         for dst, src in self._late_adds:                    # second uses of a parameter whose first gradient was a deferred fill
             dst.add_(src)
         self._late_adds, self._pending_fill = [], []
+        for p in self._late_ready:
+            self.grad_sink.mark_ready(p)
+        self._late_ready = []
+
+    def backward(self):
+        self._wgrad_deferred = [] if ((self.grad_sink is None or self._defer_under_sink) and _defer_wgrad_reduce()) else None
+        for step in reversed(self.steps):
+            step()
+        self.steps = []
+        self._flush_deferred()
+        self._wgrad_deferred = None
         if self._deferred_unscale:
             torch._foreach_mul_(self._deferred_unscale, self.inv)
             self._deferred_unscale = []

@@ -52,7 +52,7 @@ class TUTape(Tape):
     # only 4,704 rows to reduce over and 36-144 output tiles: filling 256 CUs took a 7-9-way split-K whose slabs cost more
     # than the GEMM.  288 GB of HBM keep the ~0.8 GB of operands alive until then.
     def _defer_wgrad(self, weight, x, tx, dy, gw, s_co, s_ci):
-        if tx is not None or self.grad_sink is not None or self.dtype != torch.float16 or _no_wgrad_group():
+        if tx is not None or self.dtype != torch.float16 or _no_wgrad_group():
             return False
         key = (tuple(x.shape), x.stride(), tuple(dy.shape), dy.stride(), s_co, s_ci)
         self._wgrad_groups.setdefault(key, []).append((x, dy, gw))
@@ -132,22 +132,38 @@ class TUTape(Tape):
 
     def _wstd_slot(self, ent, w):
         """(gradient w.r.t. the standardised weight, parameter gradient) views of this conv in two flat per-step buffers; the
-        second is filled by ONE umi_wstd_bwd_multi launch when the backward pass ends.  None where that deferral is not safe:
-        a gradient sink wants its own buffers filled as the pass proceeds, and a conv used twice has ONE slot (its second
-        gradient is computed at once and added after the flush, Tape._set_pgrad)."""
-        if self.grad_sink is not None or id(w) in self.param_grads or any(e is ent for e in self._wstd_pending):
+        second is filled by ONE umi_wstd_bwd_multi launch at the next flush (under a gradient sink it IS the parameter's bucket
+        slot).  None where that deferral is not safe: a conv used twice has ONE slot (its second gradient is computed at once and
+        added after the flush, Tape._set_pgrad)."""
+        if id(w) in self.param_grads or any(e is ent for e in self._wstd_pending):
+            return None
+        sink_slot = self.grad_sink.buffer_for(w) if self.grad_sink is not None else None
+        if self.grad_sink is not None and sink_slot is None:
             return None
         if self._wstd_flat is None:
             n = self.pack_cache.wstd_total
             self._wstd_flat = (torch.empty(n, dtype=torch.float32, device=w.device),
-                               torch.empty(n, dtype=torch.float32, device=w.device))
+                               torch.empty(n, dtype=torch.float32, device=w.device) if self.grad_sink is None else None)
         self._wstd_pending.append(ent)
-        return tuple(f[ent.off:ent.off + w.numel()].view(w.shape) for f in self._wstd_flat)
+        gws = self._wstd_flat[0][ent.off:ent.off + w.numel()].view(w.shape)
+        if sink_slot is not None:              # the launch writes the parameter gradient straight into the bucket slot
+            return gws, sink_slot
+        return gws, self._wstd_flat[1][ent.off:ent.off + w.numel()].view(w.shape)
+
+    _defer_under_sink = True
 
     def backward(self):
         self._wstd_pending, self._wstd_flat = [], None
         self._wgrad_groups, self._readonly, self._colsum_groups = {}, set(), {}
         super().backward()
+
+    def flush_mark(self):
+        """Marks a point of the forward pass: when the backward pass comes back to it, every deferred gradient fill recorded so far
+        runs.  Without a gradient sink this does nothing (one flush at the end is the fewest launches); under one, the model puts
+        a mark between the ResNet hybrid and the ViT encoder, so the encoder's ~85 M gradient values (the first two thirds of a
+        R50-ViT-B/16's buckets in reduction order) are on the wire while the hybrid's backward pass computes."""
+        if self.record and self.grad_sink is not None:
+            self.steps.append(self._flush_deferred)
 
     def _finish_param_grads(self):
         self._flush_wgrad_groups()
@@ -159,7 +175,10 @@ class TUTape(Tape):
             ops_tu.gn_param_grads_group(parts, n_, dgs, dbs, self.inv)
         self._gn_pending = []
         if self._wstd_pending:
-            self.pack_cache.wstd_bwd(self._wstd_pending, *self._wstd_flat)
+            slots = None
+            if self.grad_sink is not None:
+                slots = [self.grad_sink.buffer_for(e.w()) for e in self._wstd_pending]
+            self.pack_cache.wstd_bwd(self._wstd_pending, self._wstd_flat[0], self._wstd_flat[1], slots)
             self._wstd_pending = []
 
     @staticmethod
@@ -192,13 +211,12 @@ class TUTape(Tape):
                     return
                 dx = self.alloc(N, H, W, C, device=out.device)
                 dres = self.alloc(N, H, W, C, device=out.device) if (residual is not None and _wants_grad(residual)) else None
-                if (self.grad_sink is None and self.dtype == torch.float16 and id(gn.weight) not in self.param_grads
+                if (self.dtype == torch.float16 and id(gn.weight) not in self.param_grads
                         and id(gn.bias) not in self.param_grads):
-                    # dgamma / dbeta of all GroupNorm layers are summed from their per-sample rows at the end of the pass
+                    # dgamma / dbeta of all GroupNorm layers are summed from their per-sample rows at the next flush
                     part = ops_tu.gn_bwd(o.grad, out, a.raw, mean, rstd, g32, gn.num_groups, relu, dx, dres, self.inv,
                                          keep_part=True)
-                    dg, db = torch.empty(C, dtype=torch.float32, device=out.device), torch.empty(C, dtype=torch.float32,
-                                                                                                  device=out.device)
+                    dg, db = self._new_pgrad(gn.weight), self._new_pgrad(gn.bias)
                     self._gn_pending.append((part, N, dg, db))
                     self._mark_deferred_fill(dg, db)
                 else:
@@ -291,11 +309,10 @@ class TUTape(Tape):
                 if o.grad is None:
                     return
                 dx = self.alloc(N, H, W, C, device=out.device)
-                if (self.grad_sink is None and self.dtype == torch.float16 and id(ln.weight) not in self.param_grads
+                if (self.dtype == torch.float16 and id(ln.weight) not in self.param_grads
                         and id(ln.bias) not in self.param_grads):
                     part, rows = ops_tu.ln_bwd(o.grad, a.raw, g32, mean, rstd, dx, self.inv, keep_part=True)
-                    dg, db = torch.empty(C, dtype=torch.float32, device=out.device), torch.empty(C, dtype=torch.float32,
-                                                                                                  device=out.device)
+                    dg, db = self._new_pgrad(ln.weight), self._new_pgrad(ln.bias)
                     self._gn_pending.append((part, rows, dg, db))        # summed with the GroupNorm rows at the end of the pass
                     self._mark_deferred_fill(dg, db)
                 else:
@@ -441,15 +458,29 @@ class TUTape(Tape):
                     return
                 dqkv = self.alloc(N, H, W, 3 * C, device=out.device)
                 ops_tu.attn_bwd(q, k, v, out, o.grad, lse, *(dqkv[..., i * C:(i + 1) * C] for i in range(3)), heads)
-                gw = torch.empty(3 * C, C, dtype=torch.float32, device=out.device)
-                if not self._defer_wgrad(query.weight, a.raw, a.tx, dqkv, gw, C, 1):
-                    ops.conv_wgrad(a.raw, a.tx, dqkv, None, gw, C, 1, 1, self.inv, 1, 1, 1, 0)
-                gb = torch.empty(3 * C, dtype=torch.float32, device=out.device)
-                if not self._defer_colsum(dqkv, gb):
-                    ops.colsum(dqkv, gb, self.inv)
-                for i, m in enumerate(mods):
-                    self._set_pgrad(m.weight, gw[i * C:(i + 1) * C])
-                    self._set_pgrad(m.bias, gb[i * C:(i + 1) * C])
+                if self.grad_sink is not None:
+                    # three items of the grouped launches, each writing its own bucket slot (the fused [3C, C] gradient would
+                    # have to be copied into the three slots afterwards)
+                    for i, m in enumerate(mods):
+                        d_i = dqkv[..., i * C:(i + 1) * C]
+                        gw = self._new_pgrad(m.weight)
+                        if not self._defer_wgrad(m.weight, a.raw, a.tx, d_i, gw, C, 1):
+                            ops.conv_wgrad(a.raw, a.tx, d_i, None, gw, C, 1, 1, self.inv, 1, 1, 1, 0)
+                        self._set_pgrad(m.weight, gw)
+                        gb = self._new_pgrad(m.bias)
+                        if not self._defer_colsum(d_i, gb):
+                            ops.colsum(d_i, gb, self.inv)
+                        self._set_pgrad(m.bias, gb)
+                else:
+                    gw = torch.empty(3 * C, C, dtype=torch.float32, device=out.device)
+                    if not self._defer_wgrad(query.weight, a.raw, a.tx, dqkv, gw, C, 1):
+                        ops.conv_wgrad(a.raw, a.tx, dqkv, None, gw, C, 1, 1, self.inv, 1, 1, 1, 0)
+                    gb = torch.empty(3 * C, dtype=torch.float32, device=out.device)
+                    if not self._defer_colsum(dqkv, gb):
+                        ops.colsum(dqkv, gb, self.inv)
+                    for i, m in enumerate(mods):
+                        self._set_pgrad(m.weight, gw[i * C:(i + 1) * C])
+                        self._set_pgrad(m.bias, gb[i * C:(i + 1) * C])
                 if _wants_grad(a):
                     dx = self.alloc(N, H, W, C, device=out.device)
                     ops.conv_fwd(dqkv, None, packed("conv_dgrad"), None, dx, 1, 1, 1, 0)

@@ -308,26 +308,28 @@ class PackCache:
             e.ver = ver
         return e
 
-    def _wstd_table(self, ents):
+    def _wstd_table(self, ents, dws=None):
         import numpy as np
-        tkey = ("wstd",) + tuple((id(e), e.w().data_ptr()) for e in ents)
+        tkey = ("wstd",) + tuple((id(e), e.w().data_ptr()) for e in ents) + (tuple(t.data_ptr() for t in dws) if dws else ())
         tab = self._tables.get(tkey)
         if tab is None:
             arr = np.zeros(len(ents), dtype=_WSTD_DESC)
             b0 = 0
             for i, e in enumerate(ents):
                 w = e.w()
-                arr[i] = (w.data_ptr(), e.ws.data_ptr(), e.rstd.data_ptr(), e.off, w.shape[0], w[0].numel(), e.eps, b0)
+                arr[i] = (w.data_ptr(), e.ws.data_ptr(), e.rstd.data_ptr(), e.off, w.shape[0], w[0].numel(), e.eps, b0,
+                          dws[i].data_ptr() if dws else 0)
                 b0 += w.shape[0]
             tab = self._tables[tkey] = (self._upload(arr), b0, len(ents))
         return tab
 
-    def wstd_bwd(self, ents, g_flat, dw_flat):
-        """dw_flat[e.off:...] <- backward of the standardisation for every entry, from the gradients w.r.t. the standardised
-        weights in g_flat (same offsets): one launch."""
-        dev_ptr, rows, n = self._wstd_table(ents)
-        L.check(L.fn("umi_wstd_bwd_multi")(dev_ptr, n, rows, g_flat.data_ptr(), dw_flat.data_ptr(), _stream()),
-                "umi_wstd_bwd_multi")
+    def wstd_bwd(self, ents, g_flat, dw_flat, dws=None):
+        """Backward of the standardisation for every entry, from the gradients w.r.t. the standardised weights in g_flat (at
+        e.off), in one launch: into dw_flat[e.off:...], or -- `dws`: one fp32 tensor per entry, e.g. the slots of a gradient
+        sink's buckets -- straight into those."""
+        dev_ptr, rows, n = self._wstd_table(ents, dws)
+        L.check(L.fn("umi_wstd_bwd_multi")(dev_ptr, n, rows, g_flat.data_ptr(), dw_flat.data_ptr() if dw_flat is not None else None,
+                                           _stream()), "umi_wstd_bwd_multi")
 
     def _repack(self, items):
         """items: [(key, entry, source tensor)] -> one umi_pack_kn_multi launch per storage dtype."""
@@ -393,9 +395,9 @@ def _np_dtypes():
                      ("ldn", "i4"), ("pad", "i4")])
     opt = np.dtype([("p", "u8"), ("g", "u8"), ("s0", "u8"), ("s1", "u8"), ("n", "i8"), ("blk0", "i4"), ("pad", "i4")])
     wstd = np.dtype([("w", "u8"), ("ws", "u8"), ("rstd", "u8"), ("off", "i8"), ("Co", "i4"), ("K", "i4"), ("eps", "f4"),
-                     ("blk0", "i4")])
+                     ("blk0", "i4"), ("dw", "u8")])
     # sizeof(umi_pack_desc) / sizeof(umi_optim_desc) / sizeof(umi_wstd_desc)
-    assert pack.itemsize == 80 and opt.itemsize == 48 and wstd.itemsize == 48
+    assert pack.itemsize == 80 and opt.itemsize == 48 and wstd.itemsize == 56
     return pack, opt, wstd
 
 
