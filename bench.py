@@ -240,17 +240,21 @@ def main():
     # capture, which itself executes nothing.  Data parallel: eager (the RCCL all-reduce is not captured).
     graphed = None
     path_ms = {}
-    ddp_launch = "eager" if (a.eager or os.environ.get("UMI_BENCH_GRAPH", "1") == "0") else os.environ.get("UMI_DDP_LAUNCH", "auto")
+    # N > 1 reports the OVERLAPPED path by default (bucket all-reduces issued while the backward pass still computes: the
+    # north_star's exchange); the deferred-graph path is timed beside it during the warm-up and reported only on request
+    # (UMI_DDP_LAUNCH=auto: whichever is faster; =graph: always), labelled as not overlapped.
+    ddp_launch = "eager" if (a.eager or os.environ.get("UMI_BENCH_GRAPH", "1") == "0") else os.environ.get("UMI_DDP_LAUNCH", "both")
     eager_step = step
-    if world > 1 and ddp_launch in ("auto", "graph"):
+    if world > 1 and ddp_launch in ("auto", "graph", "both"):
         # Data parallel has two launch paths:
         #   eager: every launch issued from Python, bucket all-reduces overlapped with the rest of the backward pass;
         #   graph: forward + loss + backward replayed from a HIP graph that writes the gradients straight into the reducer's
         #          flat buckets, then the bucket all-reduces (RCCL, eager) and the one-launch optimizer step.  ~10 host-issued
         #          launches per step instead of ~350, but the 124 MB of gradients are reduced after the backward pass.
-        # Which one is faster depends on the host (measured on this pool at N=1: eager 24.8 .. 31.7 ms, graph 23.9 .. 25.2 ms),
-        # so "auto" times three steps of each during the warm-up and keeps the faster; every rank takes the same decision
-        # (MAX over ranks of each timing).  The graph is captured FIRST: a loss tensor kept from an eager step would hold
+        # Which one is faster depends on the host (measured on this pool at N=1: eager 24.8 .. 31.7 ms, graph 23.9 .. 25.2 ms):
+        # three steps of each are timed during the warm-up (MAX over ranks) and both figures go into the JSON line.  The
+        # timed region then runs the overlapped eager path ("both", the default), the faster of the two ("auto") or the
+        # graph ("graph"); every rank takes the same decision.  The graph is captured FIRST: a loss tensor kept from an eager step would hold
         # that step's autograd graph alive and with it gradient accumulators bound to the default stream, which crashes
         # hipStreamEndCapture (umi/graphs.py).
         from umi.graphs import GraphedStep
@@ -312,7 +316,7 @@ def main():
         reducer.deferred = False
         reducer.reset()                                  # a failed capture leaves buckets marked but never flushed
         t_eager = float("inf")
-        if ddp_launch == "auto" or graph_step is None:
+        if ddp_launch in ("auto", "both") or graph_step is None:
             for _ in range(max(1, a.warmup)):
                 eager_step()
             t_eager = timed(eager_step, 3)
@@ -324,7 +328,7 @@ def main():
         if rank == 0:
             print(f"[bench] launch paths at N={world}: graph {1e3 * t_graph:.2f} ms/step, eager {1e3 * t_eager:.2f} ms/step",
                   file=sys.stderr)
-        if graph_step is not None and t_graph <= t_eager:
+        if graph_step is not None and ddp_launch != "both" and (ddp_launch == "graph" or t_graph <= t_eager):
             reducer.deferred = True
             step, graphed = graph_step, gs
         else:
@@ -351,10 +355,11 @@ def main():
             torch.cuda.empty_cache()                     # drop the failed capture's private pool
             for _ in range(3):                           # the side-stream warm-up cached its blocks for another stream
                 step()
-    if graphed is None and not (world > 1 and ddp_launch in ("auto", "graph")):
+    if graphed is None and not (world > 1 and ddp_launch in ("auto", "graph", "both")):
         for _ in range(a.warmup):
             step()
-    launch = "eager" if graphed is None else ("hipgraph" if world == 1 else "hipgraph(fwd+bwd) + eager all-reduce + optimizer")
+    launch = ("eager" if world == 1 else "eager launches, bucket all-reduces overlapped with the backward pass") if graphed is None else (
+        "hipgraph" if world == 1 else "hipgraph(fwd+bwd), then all-reduce (NOT overlapped) + optimizer")
 
     def fence():
         torch.cuda.synchronize()
