@@ -79,6 +79,17 @@ int umi_conv_fwd(const void* x, int ldx, const void* tx, const void* wp, const f
                  int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad,
                  int Ho, int Wo, int off_h, int off_w, int out_H, int out_W,
                  int in_dtype, int out_dtype, int flags, umi_stream_t stream);
+/* A ViT-block linear with its elementwise tail in the GEMM epilogue (reference TransUnet/vit_seg_modeling.py:113-119 Mlp.forward,
+ * :177-187 Block.forward), fp16 storage:
+ *   epi 1: y = x W + b, y2 = dropout(GELU(y)), mask        (fc1: y is kept for the GELU backward)
+ *   epi 2: y = dropout(x W + b) + aux, mask                (fc2 / attention output projection, aux = the block's residual)
+ * x [M, Ci], y / y2 / aux [M, Co] (ld in elements), wp8 = umi_pack_kn8 of the [Co, Ci] weight, mask: M*Co bytes (as umi_dropout).
+ * Same values, random stream and roundings as umi_conv_fwd followed by umi_dropout_fused.  UMI_ERR_UNSUPPORTED where the
+ * pointwise matrix-core kernel does not apply (run the two calls). */
+int umi_linear_fused(const void* x, int ldx, const void* wp8, const float* bias, void* y, int ldy, long M, int Ci, int Co,
+                     int epi, float p, unsigned seed, const unsigned* seed_dev, void* mask, const void* aux, int ldaux,
+                     void* y2, int ldy2, int dtype, umi_stream_t stream);
+
 /* Which kernel umi_conv_fwd will take for this problem: *layout = 0 -> weights packed with umi_pack_kn,
  * 1 -> umi_pack_kn8 (MFMA path: fp16, 3x3, stride 1, pad 1, Ci%16==0, Co%64==0, no bias, 16-B aligned
  * rows); *stat_rows = rows of `stat_part` the call will write. */

@@ -661,3 +661,40 @@ def test_pack_cache_wstd_and_side_by_side_operands_match_the_single_launch_paths
     for w, e in zip(convs, ents):
         gw = gflat[e.off:e.off + w.numel()].view(w.shape)
         assert torch.equal(dflat[e.off:e.off + w.numel()].view(w.shape), T.wstd_bwd(e.ws, e.rstd, gw.contiguous()))
+
+
+@pytest.mark.parametrize("M,Ci,Co", [(4704, 768, 3072), (300, 256, 128), (77, 64, 192)])
+def test_linear_fused_epilogues_match_the_two_kernel_sequence(M, Ci, Co):
+    """umi_linear_fused (GEMM epilogue = bias + GELU + dropout -> second output + mask bytes; or bias + dropout + residual add)
+    against umi_conv_fwd followed by umi_dropout_fused with the same seed: identical outputs and masks, bit for bit
+    (reference vit_seg_modeling.py:113-119 Mlp.forward, :177-187 Block.forward)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    from umi import ops, ops_tu
+    g = torch.Generator(device=DEV).manual_seed(M + Ci)
+    x = torch.randn(1, 1, M, Ci, device=DEV, generator=g).half()
+    w = torch.randn(Co, Ci, 1, 1, device=DEV, generator=g) * Ci ** -0.5
+    b = torch.randn(Co, device=DEV, generator=g) * 0.1
+    res = torch.randn(1, 1, M, Co, device=DEV, generator=g).half()
+    seed_dev = torch.tensor([5], dtype=torch.int32, device=DEV)
+    p, seed = 0.1, 1234567
+    y = torch.empty(1, 1, M, Co, device=DEV, dtype=torch.float16)
+    lay, _ = ops.conv_plan(x, y, 1, 1, 1, 0, has_bias=True)
+    assert lay == 1
+    wp = ops.pack_conv_fwd(w, torch.float16, k8=True)
+    ops.conv_fwd(x, None, lambda l: wp, b, y, 1, 1, 1, 0)
+    for epi in (1, 2):
+        ref_out, ref_mask = torch.empty_like(y), torch.empty(M * Co, dtype=torch.uint8, device=DEV)
+        assert ops_tu.dropout_fused(y, ref_out, ref_mask, False, p, seed, seed_dev, None if epi == 1 else res, epi == 1)
+        yf = torch.full_like(y, 7.0)
+        y2 = torch.full_like(y, 7.0) if epi == 1 else None
+        mask = torch.zeros(M * Co, dtype=torch.uint8, device=DEV)
+        assert ops_tu.linear_fused(x, wp, b, yf, epi, p, seed, seed_dev, mask, aux=res if epi == 2 else None, y2=y2)
+        torch.cuda.synchronize()
+        assert torch.equal(mask, ref_mask)
+        assert 0.05 < 1.0 - mask.float().mean().item() < 0.15          # about p of the elements dropped
+        if epi == 1:
+            assert torch.equal(yf, y)                                   # the pre-activation, kept for the GELU backward
+            assert torch.equal(y2, ref_out)
+        else:
+            assert torch.equal(yf, ref_out)

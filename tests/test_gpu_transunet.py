@@ -420,3 +420,32 @@ def test_block_applied_twice_in_one_tape_accumulates_both_gradients():
         if k == "attn.key.bias":                   # softmax is invariant to a shift of the keys: this gradient is rounding noise
             continue
         assert rel(p.grad, rp.grad) < 6e-2, (k, rel(p.grad, rp.grad))      # a dropped second contribution is off by ~0.5-1
+
+
+@pytest.mark.gpu
+def test_fused_linear_epilogues_leave_the_dropout_training_step_unchanged(monkeypatch):
+    """TransUNet with dropout 0.1 in train mode, fp16: the step with the ViT linears' GELU / dropout / residual tails in the GEMM
+    epilogues (umi_linear_fused) equals the step with the separate kernels (UMI_NO_LINEAR_FUSION=1) bit for bit -- logits and
+    every parameter gradient (same counter-based random stream)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs an MI355X")
+    import loss as L
+    from TransUnet.vit_seg_modeling import VisionTransformer
+    cfg = ref_transunet.small_config(2)
+    cfg["dropout_rate"] = 0.1
+    L.CLASS_NUMBER = 2
+    x, lab = recipe.synthetic_batch(2, 1, 64, 64, 2, seed=9)
+    outs = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("UMI_NO_LINEAR_FUSION", off)
+        torch.manual_seed(11)
+        m = VisionTransformer(product_config(cfg, 64), img_size=64, num_classes=2, compute_dtype="fp16")
+        m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=9, negative_gamma=False))
+        m.to(DEV).train()
+        torch.manual_seed(12)                      # the model draws its dropout base seed from torch's generator
+        logits = m(x.to(DEV))
+        L.calc_loss(logits, lab.to(DEV), loss_type="dice_bce_mc").backward()
+        outs.append((logits.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)

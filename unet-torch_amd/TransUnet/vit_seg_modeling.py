@@ -271,13 +271,13 @@ def _build_attention(t, x, attn: Attention, residual=None):
     if attn.attn_dropout.p > 0 and t.training:
         raise NotImplementedError("attention-probability dropout > 0 is not supported (all reference configs use 0.0)")
     ctx = t.qkv_attention(x, attn.query, attn.key, attn.value, attn.num_attention_heads)
-    return t.dropout(t.linear(ctx, attn.out.weight, attn.out.bias), attn.proj_dropout.p, add=residual)
+    return t.linear_dropout(ctx, attn.out.weight, attn.out.bias, attn.proj_dropout.p, add=residual)
 
 
 def _build_mlp(t, x, mlp: Mlp, residual=None):
     """`residual`: the block's skip input, added by the last dropout's kernel (Block.forward's `x + h`)."""
-    x = t.dropout(t.linear(x, mlp.fc1.weight, mlp.fc1.bias), mlp.dropout.p, gelu=True)
-    return t.dropout(t.linear(x, mlp.fc2.weight, mlp.fc2.bias), mlp.dropout.p, add=residual)
+    x = t.linear_dropout(x, mlp.fc1.weight, mlp.fc1.bias, mlp.dropout.p, gelu=True)
+    return t.linear_dropout(x, mlp.fc2.weight, mlp.fc2.bias, mlp.dropout.p, add=residual)
 
 
 def _build_block(t, h, blk: Block, cfg=None):

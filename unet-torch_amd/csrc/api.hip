@@ -23,9 +23,10 @@ int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, vo
 // conv1x1_mfma.hip
 bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int ldy, int in_dtype,
                          int out_dtype, int flags);
+struct UmiLinearEpi { int mode; float p; unsigned seed; const unsigned* seed_dev; void* mask; const void* aux; int ldaux; void* y2; int ldy2; };
 int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y, int ldy,
                      int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int off_h,
-                     int off_w, int out_H, int out_W, int flags, hipStream_t s);
+                     int off_w, int out_H, int out_W, int flags, hipStream_t s, const UmiLinearEpi* epi = nullptr);
 // stem_head.hip
 bool umi_stem_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldy, int in_dtype, int out_dtype, int flags,
                      const float* bias);
@@ -96,6 +97,25 @@ int umi_wgrad3x3_mfma(const void* x, int ldx, const void* txa, const void* dy, i
 
 extern "C" int umi_version(void) { return 1; }
 extern "C" const char* umi_arch(void) { return "gfx950"; }
+
+// A ViT-block linear with its elementwise tail in the GEMM epilogue (reference vit_seg_modeling.py:113-119 Mlp, :177-187 Block):
+//   epi 1: y = x W + b,  y2 = dropout(GELU(y)),  mask          (fc1; y stays for the GELU backward)
+//   epi 2: y = dropout(x W + b) + aux,           mask          (fc2 / attention output projection + residual)
+// x [M, Ci], y / y2 / aux [M, Co] fp16 rows (ld in elements), wp8 = umi_pack_kn8 of the [Co, Ci] weight, mask = M * Co bytes.
+// Same values as umi_conv_fwd followed by umi_dropout_fused (same random stream and roundings).  UMI_ERR_UNSUPPORTED where
+// the pointwise matrix-core kernel does not apply: run the two calls instead.
+extern "C" int umi_linear_fused(const void* x, int ldx, const void* wp8, const float* bias, void* y, int ldy, long M, int Ci,
+                                int Co, int epi, float p, unsigned seed, const unsigned* seed_dev, void* mask, const void* aux,
+                                int ldaux, void* y2, int ldy2, int dtype, umi_stream_t stream) {
+    if (!x || !wp8 || !y || !mask || M <= 0 || M >= (1L << 31) || Ci <= 0 || Co <= 0 || p < 0.f || p >= 1.f) return UMI_ERR_BADARG;
+    if (epi != 1 && epi != 2) return UMI_ERR_BADARG;
+    if ((epi == 1 && (!y2 || ldy2 % 8)) || (epi == 2 && (!aux || ldaux % 8))) return UMI_ERR_BADARG;
+    if (dtype != UMI_F16 || !umi_conv1x1_mfma_ok(Ci, Co, 1, 1, 1, 0, ldx, ldy, UMI_F16, UMI_F16, 0)) return UMI_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wp8 | (uintptr_t)y2 | (uintptr_t)aux) & 15 || ((uintptr_t)mask & 7)) return UMI_ERR_UNSUPPORTED;
+    const UmiLinearEpi e{epi, p, seed, seed_dev, mask, aux, ldaux, y2, ldy2};
+    return umi_conv1x1_mfma(x, ldx, nullptr, wp8, bias, y, ldy, 1, 1, (int)M, Ci, Co, 1, 1, 1, 0, 1, (int)M, 0, 0, 1, (int)M, 0,
+                            (hipStream_t)stream, &e);
+}
 
 extern "C" int umi_conv_fwd_plan(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int ldx,
                                  int ldy, int in_dtype, int out_dtype, int flags, int has_bias, int* layout,

@@ -25,6 +25,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// epilogue fusion request of umi_linear_fused (api.hip); mode 0 = none
+struct UmiLinearEpi { int mode; float p; unsigned seed; const unsigned* seed_dev; void* mask; const void* aux; int ldaux; void* y2; int ldy2; };
+
 namespace {
 
 constexpr int OUT_UPS_TAPS_MAX = 49;     // most taps a packed weight tensor of this kernel has (R*S <= 49)
@@ -40,7 +43,26 @@ struct Geo {                  // geometry of the (optionally strided) source / d
     int Hd, Wd, doy, dox;     // destination dims (+ offset)          ; for OUT_UPS dest pixel = (2y+dy+doy, 2x+dx+dox)
     int S, stride, pad, frac; // GATHER: taps per row, stride, padding; frac = data gradient of a strided conv
     int accum;                // UMI_CONV_ACCUMULATE: y += result (fp16 add of the stored and the new value)
+    // Epilogue fusions of the ViT block's linears (plain dense mode only; reference vit_seg_modeling.py:113-119,177-187), the
+    // arithmetic of elementwise_tu_f16.hip's dropout8_fused_kernel on the fp16 values the unfused GEMM would have stored --
+    // same random stream (element index, seed), same mask bytes, same roundings, so fused == unfused bit for bit:
+    //   epi 1 (fc1):            y = x W + b (kept for the GELU backward),  y2 = dropout(gelu(y)),  mask
+    //   epi 2 (fc2 / attn out): y = dropout(x W + b) + aux,                                          mask
+    int epi;
+    float drop_p;
+    unsigned seed;
+    const unsigned* seed_dev;
+    unsigned char* mask;
+    const half_t* aux; int ldaux;
+    half_t* y2; int ldy2;
 };
+
+__device__ __forceinline__ float c1_gelu(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ unsigned c1_hash32(unsigned a, unsigned b) {            // == elementwise_tu_f16.hip hash32
+    unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
 
 // Workgroups per CU: the 128 x 64 tiles keep 32 accumulators and fit 128 VGPRs, so FOUR of their workgroups share a CU (4 x 33 KB
 // of LDS): the counters of the 4,704-token linears (tools/experiments/pmc_gemm.py) show waves parked at s_waitcnt / barriers
@@ -326,6 +348,30 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
                 const half8 o = *reinterpret_cast<const half8*>(dst);
                 v = __builtin_bit_cast(uint4, (half8)(o + __builtin_bit_cast(half8, v)));
             }
+            if (geo.epi) {                  // dense mode (the launcher guarantees it): row m0 + p, columns cop .. cop + 7
+                const long e0 = (m0 + p) * (long)Ntot_ + cop;
+                const unsigned seed = geo.seed + (geo.seed_dev ? geo.seed_dev[0] * 0x9E3779B9u : 0u);
+                const float scale = 1.f / (1.f - geo.drop_p);
+                const half8 xv = __builtin_bit_cast(half8, v);
+                half8 av, o;
+                if (geo.epi == 2) av = *reinterpret_cast<const half8*>(geo.aux + (m0 + p) * geo.ldaux + cop);
+                unsigned long long mk = 0;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const long e = e0 + jj;
+                    const float u = (c1_hash32((unsigned)e, seed ^ (unsigned)(e >> 32)) >> 8) * (1.f / 16777216.f);
+                    const unsigned k = u >= geo.drop_p;
+                    mk |= (unsigned long long)k << (8 * jj);
+                    float f = (float)xv[jj];
+                    if (geo.epi == 1) f = c1_gelu(f);
+                    f = k ? f * scale : 0.f;
+                    if (geo.epi == 2) f += (float)av[jj];
+                    o[jj] = (half_t)f;
+                }
+                *reinterpret_cast<unsigned long long*>(geo.mask + e0) = mk;
+                if (geo.epi == 1) *reinterpret_cast<half8*>(geo.y2 + (m0 + p) * geo.ldy2 + cop) = o;
+                else v = __builtin_bit_cast(uint4, o);
+            }
             *reinterpret_cast<uint4*>(dst) = v;
         }
     }
@@ -378,8 +424,9 @@ bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int 
 
 int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y, int ldy,
                      int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int off_h,
-                     int off_w, int out_H, int out_W, int flags, hipStream_t s) {
+                     int off_w, int out_H, int out_W, int flags, hipStream_t s, const UmiLinearEpi* epi) {
     const int mode = umi_conv1x1_mode(R, S, stride, pad, flags);
+    if (epi && epi->mode && (mode != 0 || (flags & UMI_CONV_ACCUMULATE) || Co % 8)) return UMI_ERR_UNSUPPORTED;
     Geo geo;
     long M;
     int Kc = Ci, Nc = Co, Ntot = Co, ntaps = 1;
@@ -405,6 +452,13 @@ int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, co
     const long b_256_128 = ((M + 255) / 256) * (Ntot / 128), b_128_128 = ((M + 127) / 128) * (Ntot / 128);
     const long b_256_64 = ((M + 255) / 256) * (Ntot / 64);
     geo.accum = (flags & UMI_CONV_ACCUMULATE) ? 1 : 0;
+    geo.epi = 0; geo.drop_p = 0.f; geo.seed = 0; geo.seed_dev = nullptr; geo.mask = nullptr; geo.aux = nullptr; geo.ldaux = 0;
+    geo.y2 = nullptr; geo.ldy2 = 0;
+    if (epi && epi->mode) {
+        geo.epi = epi->mode; geo.drop_p = epi->p; geo.seed = epi->seed; geo.seed_dev = epi->seed_dev;
+        geo.mask = (unsigned char*)epi->mask; geo.aux = (const half_t*)epi->aux; geo.ldaux = epi->ldaux;
+        geo.y2 = (half_t*)epi->y2; geo.ldy2 = epi->ldy2;
+    }
 #define GO(P_, BN_) return launch<P_, BN_>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s)
     // UMI_C1_TILE=PxBN: tile override for timing experiments (tools/ab_gemm.py); read per call
     if (const char* e = getenv("UMI_C1_TILE")) {

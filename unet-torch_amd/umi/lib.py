@@ -5,7 +5,7 @@ missing and cannot be built, importing this module raises.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_uint, c_void_p
 
 from . import build as _build
 
@@ -38,6 +38,8 @@ SIGNATURES = {
     "umi_version": (c_int, []),
     "umi_arch": (c_char_p, []),
     "umi_tune_conv3x3_impl": (c_int, [c_int]),
+    "umi_linear_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_float,
+                                 c_uint, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "umi_pack_kn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_int, c_int,
                             c_int, c_void_p]),
     "umi_pack_kn8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_int, c_int,

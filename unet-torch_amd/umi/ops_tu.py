@@ -154,6 +154,21 @@ def dropout_fused(x, y, mask, backward, p, seed, seed_dev=None, aux=None, gelu=F
     return True
 
 
+def linear_fused(x, wp8, bias, y, epi, p, seed, seed_dev, mask, aux=None, y2=None):
+    """umi_linear_fused: y = x W + b with the block's elementwise tail in the GEMM epilogue (epi 1: y2 = dropout(gelu(y));
+    epi 2: y = dropout(x W + b) + aux).  False where the matrix-core kernel does not apply (nothing was launched)."""
+    M, Ci, ldx = _rows(x)
+    _, Co, ldy = _rows(y)
+    st = L.fn("umi_linear_fused")(x.data_ptr(), ldx, wp8.data_ptr(), _ptr(bias), y.data_ptr(), ldy, M, Ci, Co, int(epi), p,
+                                  seed & 0xFFFFFFFF, _ptr(seed_dev), mask.data_ptr(), _ptr(aux),
+                                  _rows(aux)[2] if aux is not None else 0, _ptr(y2), _rows(y2)[2] if y2 is not None else 0,
+                                  _dt(x), _stream())
+    if st == -2:
+        return False
+    L.check(st, "umi_linear_fused")
+    return True
+
+
 def attn_fwd(q, k, v, o, heads):
     B, _, N, C = q.shape
     D = C // heads
