@@ -402,6 +402,13 @@ size_t umi_znorm_ws_bytes(void);
 int umi_znorm_hwc(const void* img, int src_dtype, float* out_chw, long HW, int C, int reverse_channels, void* ws,
                   size_t ws_bytes, umi_stream_t stream);
 int umi_argmax_mask(const float* logits, unsigned char* mask, int N, int C, long HW, umi_stream_t stream);
+/* umi_zoom_cubic_hwc (test_mc3serousv5.py:100-113, the resize of `preprocess`): scipy.ndimage.zoom(img, (out_h / H, out_w / W[, 1]),
+ *   order=3) of one HWC image, C <= 4, src_dtype as umi_znorm_hwc; `out` has the input's type and [out_h][out_w][C] elements.
+ *   B-spline prefilter (float64, mirror boundaries), corner-aligned sampling, uint8 results rounded and clipped: SciPy's algorithm,
+ *   restated and pinned against SciPy by oracle/ref_resize.py.  ws: umi_zoom_cubic_ws_bytes(H, W, C). */
+size_t umi_zoom_cubic_ws_bytes(int H, int W, int C);
+int umi_zoom_cubic_hwc(const void* img, int src_dtype, void* out, int H, int W, int C, int out_h, int out_w, void* ws,
+                       size_t ws_bytes, umi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,9 @@ for name, n, h, w, ci, co in bench.double_conv_shapes(1, 64, 512, 512, 16):
         continue
     x = torch.randn(n, h, w, ci, device=dev, generator=gen).to(dt)
     wgt = torch.randn(co, ci, 3, 3, device=dev, generator=gen) * (2.0 / (9 * ci)) ** 0.5
+    if os.environ.get("AB_ZERO") == "1":        # clock experiment: all-zero operands draw less power (MI355X_MICROARCH.md, DVFS)
+        x.zero_()
+        wgt.zero_()
     tx = ops.passthrough_tx(ci, dev)
     tx[:, 1] = 0.5 + torch.rand(ci, device=dev, generator=gen)
     tx[:, 2] = 0.2 * torch.randn(ci, device=dev, generator=gen)

@@ -1,7 +1,7 @@
 """Timing-only experiment: builds conv_mfma variants (no staging / no MFMA) as separate .so files and times a few
 layers.  Results are wrong by construction for the ablated builds; only durations matter."""
 import ctypes, os, subprocess, sys, time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "unet-torch_amd")]
 import torch
 from umi import build as B

@@ -1,7 +1,7 @@
 """Diagnostic build with in-kernel s_memtime stamps: where does a main-loop iteration of conv3x3_mfma spend its cycles?
 (shares, not absolute times: the stamps' fences forbid overlaps the real kernel has)"""
 import ctypes, os, subprocess, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "unet-torch_amd")]
 import numpy as np, torch
 from umi import build as B, ops, lib as L

@@ -1,7 +1,7 @@
 """Diagnostic build with in-kernel s_memtime stamps: where does a tile iteration of wgrad3x3_mfma spend its cycles?
 (shares, not absolute times: the stamps' fences forbid overlaps the real kernel has)"""
 import ctypes, os, subprocess, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "unet-torch_amd")]
 import numpy as np, torch
 from umi import build as B, ops, lib as L
@@ -36,6 +36,8 @@ for nm, n, h, w, ci, co in [("64->64@512", 16, 512, 512, 64, 64), ("128->128@256
     if not os.environ.get("UMI_WGRAD_CLASSIC"):
         b = buf.reshape(256, 8, 8).astype(np.float64)
         b = b[b[:, 0, 5] > 0]
+        if "-DUMI_STAMP_STEPS" in sys.argv:
+            print("   consumer tile-start (B + first A fragments landed), cycles per tile:", np.median(b[:, :4, 2] / b[:, :4, 5]))
         per = b[:, :, :2] / b[:, :, 5:6]
         c, pr = np.median(per[:, :4].reshape(-1, 2), axis=0), np.median(per[:, 4:].reshape(-1, 2), axis=0)
         print(f"{nm}: {ms*1e3:.0f} us (stamped build) | per tile: consumer work {c[0]:.0f} barrier-wait {c[1]:.0f} | producer work {pr[0]:.0f} "

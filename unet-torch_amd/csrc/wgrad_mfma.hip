@@ -519,7 +519,13 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
             _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                    \
                 acc[dyi * 3 + (dx_)][ca_][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_[r + dyi], bfr[r][cb], acc[dyi * 3 + (dx_)][ca_][cb], 0, 0, 0)
 #define UMI_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef UMI_STAMP
+    unsigned long long cw = 0, cb_ = 0, cstart = 0;
+#endif
     for (int i = 0; i < ntile; ++i) {
+#ifdef UMI_STAMP
+        UMI_TW(c0);
+#endif
         const unsigned char* a_frag = smem_ws + (i & 1) * SMEM + wci * A_CHUNK + frag_lane;
         const unsigned char* b_frag = smem_ws + (i & 1) * SMEM + A_BYTES + wco * B_CHUNK + frag_lane;
         half8 a0[TR + 2], a1[TR + 2], bfr[TR][2];
@@ -528,14 +534,37 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) bfr[r][cb] = tr_frag(b_frag + (r * 32) * PROW + cb * 32);
         UMI_LD_A16(a0, 0, 0); UMI_PIN();
+#ifdef UMI_STAMP_STEPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        UMI_TW(cs0);
+        cstart += cs0 - c0;
+#endif
         UMI_LD_A16(a1, 1, 0); UMI_PIN(); UMI_MMA16(a0, 0, 0); UMI_PIN();
         UMI_LD_A16(a0, 0, 1); UMI_PIN(); UMI_MMA16(a1, 1, 0); UMI_PIN();
         UMI_LD_A16(a1, 1, 1); UMI_PIN(); UMI_MMA16(a0, 0, 1); UMI_PIN();
         UMI_LD_A16(a0, 0, 2); UMI_PIN(); UMI_MMA16(a1, 1, 1); UMI_PIN();
         UMI_LD_A16(a1, 1, 2); UMI_PIN(); UMI_MMA16(a0, 0, 2); UMI_PIN();
         UMI_MMA16(a1, 1, 2);
+#ifdef UMI_STAMP
+        UMI_TW(c1);
+#endif
         __syncthreads();
+#ifdef UMI_STAMP
+        UMI_TW(c2);
+        cw += c1 - c0; cb_ += c2 - c1;
+#endif
     }
+#ifdef UMI_STAMP
+    {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lane == 0 && bid < 256) {
+            umi_stamp_buf_w[(bid * 8 + wave) * 8 + 0] = cw;
+            umi_stamp_buf_w[(bid * 8 + wave) * 8 + 1] = cb_;
+            umi_stamp_buf_w[(bid * 8 + wave) * 8 + 2] = cstart;
+            umi_stamp_buf_w[(bid * 8 + wave) * 8 + 5] = ntile;
+        }
+    }
+#endif
 #undef UMI_LD_A16
 #undef UMI_MMA16
 #undef UMI_PIN

@@ -38,6 +38,8 @@ SIGNATURES = {
     "umi_version": (c_int, []),
     "umi_arch": (c_char_p, []),
     "umi_tune_conv3x3_impl": (c_int, [c_int]),
+    "umi_zoom_cubic_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "umi_zoom_cubic_hwc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "umi_linear_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_float,
                                  c_uint, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "umi_pack_kn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_int, c_int,
