@@ -533,6 +533,22 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
         for (int r = 0; r < TR; ++r)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) bfr[r][cb] = tr_frag(b_frag + (r * 32) * PROW + cb * 32);
+#ifndef UMI_WS_COARSE
+        // the 12 transposing reads of step s + 1 are spread between the 24 MFMAs of step s (one read behind every MFMA pair) instead of
+        // issued as a burst in front of them: -1.5 % on the 17 layers of the bench (round 3, tools/ab_wgrad.py; UMI_WS_COARSE = the old order)
+#define UMI_STEP(ld_, mma_) do { ld_; mma_;                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }  \
+            UMI_PIN(); } while (0)
+        UMI_LD_A16(a0, 0, 0); UMI_PIN();
+        UMI_STEP(UMI_LD_A16(a1, 1, 0), UMI_MMA16(a0, 0, 0));
+        UMI_STEP(UMI_LD_A16(a0, 0, 1), UMI_MMA16(a1, 1, 0));
+        UMI_STEP(UMI_LD_A16(a1, 1, 1), UMI_MMA16(a0, 0, 1));
+        UMI_STEP(UMI_LD_A16(a0, 0, 2), UMI_MMA16(a1, 1, 1));
+        UMI_STEP(UMI_LD_A16(a1, 1, 2), UMI_MMA16(a0, 0, 2));
+        UMI_MMA16(a1, 1, 2);
+#undef UMI_STEP
+#else
         UMI_LD_A16(a0, 0, 0); UMI_PIN();
 #ifdef UMI_STAMP_STEPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -545,6 +561,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
         UMI_LD_A16(a0, 0, 2); UMI_PIN(); UMI_MMA16(a1, 1, 1); UMI_PIN();
         UMI_LD_A16(a1, 1, 2); UMI_PIN(); UMI_MMA16(a0, 0, 2); UMI_PIN();
         UMI_MMA16(a1, 1, 2);
+#endif
 #ifdef UMI_STAMP
         UMI_TW(c1);
 #endif
