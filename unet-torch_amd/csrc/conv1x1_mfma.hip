@@ -71,6 +71,11 @@ __device__ __forceinline__ unsigned c1_hash32(unsigned a, unsigned b) {         
 #ifndef UMI_C1_OCC128
 #define UMI_C1_OCC128 4
 #endif
+#ifdef UMI_X_NOMFMA
+#define UMI_X_MMA(c_, a_, b_) do { if ((ks | ct | i) == 0) c_[0] += (float)a_[0] * (float)b_[0]; } while (0)
+#else
+#define UMI_X_MMA(c_, a_, b_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0)
+#endif
 template <int P, int BN, bool GATHER, bool OUT_UPS, bool HAS_TX>
 __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) void conv1x1_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
@@ -106,7 +111,10 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
     // dense: a plain pointwise conv whose source and destination are whole tensors (token linears, bottleneck 1x1 convs): pixel m
     // is row m of both, none of the index arithmetic below (64-bit divisions: ~2 us of a 17-us launch) is needed
     const bool dense = !GATHER && !OUT_UPS && geo.Hs == geo.h && geo.Ws == geo.w && geo.Hd == geo.h && geo.Wd == geo.w;
-    const long n0img = dense ? 0 : m0 / ((long)geo.h * geo.w);     // first image of this tile: source offsets are relative to it
+    // first image of this tile: source offsets are relative to it (32-bit division wherever the pixel count allows: the 64-bit one
+    // expands to ~200 instructions)
+    const long hw_ = (long)geo.h * geo.w;
+    const long n0img = dense ? 0 : (M <= 0xFFFFFFFFL ? (long)((unsigned)m0 / (unsigned)hw_) : m0 / hw_);
     // K chunks in flight per thread (global -> registers), D - 1 of them while the matrix cores work on another: with the
     // 128-pixel tiles (ViT linears: 4,704 tokens, ~1.7 workgroups per CU) one chunk's MFMA phase is ~500 cycles against
     // ~2,000 of load latency, and with a single chunk in flight the loop ran at the latency (17 us for K = 768, 55 us for
@@ -122,22 +130,33 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
     long xoff[KPX];                           // plain: element offset of this thread's pixel k in the source, or -1
     int nH[KPX], by[KPX], bx[KPX];            // GATHER: image row base n*Hs and the tap-0 source coordinate of pixel k
     bool xv[D][KPX];                          // this pixel's piece of the chunk held in register set d exists (image and K range)
+    // (image, y, x) of the tile's first pixel: ONE 64-bit division per thread; the other pixels of the tile follow from it with
+    // small-integer quotients (float reciprocal + one correction step, exact for operands below 2^17).  Eight 64-bit divisions
+    // per thread here were ~40 % of the lifetime of a two-chunk workgroup (ConvTranspose of the 128-channel level).
+    const int r0img = dense ? 0 : (int)(m0 - n0img * (long)geo.h * geo.w);
+    const int y0img = dense ? 0 : r0img / geo.w, x0img = dense ? 0 : r0img - y0img * geo.w;
+    const float inv_w = 1.f / (float)geo.w, inv_h = 1.f / (float)geo.h;
 #pragma unroll
     for (int k = 0; k < KPX; ++k) {
-        long m = m0 + (tid >> 3) + 32 * k;
+        const int off = (tid >> 3) + 32 * k;
+        long m = m0 + off;
         xoff[k] = -1;
         nH[k] = 0; by[k] = -(1 << 28); bx[k] = 0;          // far outside: every tap of a pixel beyond M is "padding"
         if (m < M && dense) xoff[k] = (m - m0) * ldx + sub * 8;
         else if (m < M) {
-            int n = (int)(m / ((long)geo.h * geo.w));
-            int r = (int)(m - (long)n * geo.h * geo.w);
-            int yy = r / geo.w, xx = r - yy * geo.w;
-            if (sub == 0) pixinfo[(tid >> 3) + 32 * k] = make_int2(n, (yy << 16) | xx);
+            const int a = x0img + off;                     // < w + P
+            int qx = (int)((float)a * inv_w), xx = a - qx * geo.w;
+            if (xx < 0) { --qx; xx += geo.w; } else if (xx >= geo.w) { ++qx; xx -= geo.w; }
+            const int b = y0img + qx;                      // < h + P
+            int qy = (int)((float)b * inv_h), yy = b - qy * geo.h;
+            if (yy < 0) { --qy; yy += geo.h; } else if (yy >= geo.h) { ++qy; yy -= geo.h; }
+            const int nrel = qy;                           // image index relative to the tile's first image
+            if (sub == 0) pixinfo[off] = make_int2((int)n0img + nrel, (yy << 16) | xx);
             if (GATHER) {
-                nH[k] = (n - (int)n0img) * geo.Hs;
+                nH[k] = nrel * geo.Hs;
                 by[k] = geo.frac ? yy + geo.pad : yy * geo.stride - geo.pad + geo.soy;
                 bx[k] = geo.frac ? xx + geo.pad : xx * geo.stride - geo.pad + geo.sox;
-            } else xoff[k] = ((long)((long)(n - n0img) * geo.Hs + yy) * geo.Ws + xx) * ldx + sub * 8;
+            } else xoff[k] = ((long)((long)nrel * geo.Hs + yy) * geo.Ws + xx) * ldx + sub * 8;
         }
     }
     long woff[KPW];                           // element offset of weight row k (chunk 0)
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
     // (the source resource starts at the first image this tile touches -- n0img, below -- so that 31-bit offsets are enough
     // for any tensor whose single images are below 1 GB)
     const long ximg_bytes = (long)geo.Hs * geo.Ws * ldx * 2;
-    const long xleft = dense ? (M - m0) * ldx * 2 : (M / ((long)geo.h * geo.w) - n0img) * ximg_bytes;
+    const long xleft = dense ? (M - m0) * ldx * 2 : ((M <= 0xFFFFFFFFL ? (long)((unsigned)M / (unsigned)hw_) : M / hw_) - n0img) * ximg_bytes;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)x + (dense ? m0 * ldx * 2 : n0img * ximg_bytes)), 0, (int)(xleft > 0x7FFFFFF0L ? 0x7FFFFFF0L : xleft), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
                         bf[i] = *reinterpret_cast<const half8*>(smem + b_base + (ph * NT + i) * 16 * ROWB + ks * 64); \
                     _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                                              \
                         _Pragma("unroll") for (int i = 0; i < NT; ++i)                                            \
-                            acc[ct][ph * NT + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ct], bf[i], acc[ct][ph * NT + i], 0, 0, 0); \
+                            UMI_X_MMA(acc[ct][ph * NT + i], af[ct], bf[i]); \
                 }                                                                                                 \
             }                                                                                                     \
             __builtin_amdgcn_s_setprio(0);                                                                        \
@@ -372,6 +391,9 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
                 if (geo.epi == 1) *reinterpret_cast<half8*>(geo.y2 + (m0 + p) * geo.ldy2 + cop) = o;
                 else v = __builtin_bit_cast(uint4, o);
             }
+#ifdef UMI_X_NOSTORE
+            if (v.x == 0x12345678u)
+#endif
             *reinterpret_cast<uint4*>(dst) = v;
         }
     }

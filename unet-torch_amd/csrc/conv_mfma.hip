@@ -67,8 +67,20 @@ constexpr int ROWB = 48;        // LDS bytes per pixel / weight row (16 halfs + 
 // 16-channel chunk.  Used by the BN = 64 tile, i.e. the 512 x 512 layers, whose input lines do not survive in the XCD's 4 MB
 // L2 from one chunk to the next (64 resident tiles x 78 KB): measured fabric-side fetch 1.87 x the input of 64 -> 64 at
 // 512 x 512 and 2.08 x for 128 -> 64 (profiles/r03_conv_fwd_traffic.json) against 1.2 x for the halo alone.
-template <int TH, int BN, int SC = 1>
+//
+// K32 (needs SC = 2): the matrix cores run v_mfma_f32_16x16x32_f16 with K = the 32 staged channels of ONE tap.  The weights of
+// a 32-channel super-chunk (9 x BN x 64 B) do not fit next to the halo tile, so they are staged per tap COLUMN dx (3 taps x BN
+// rows of 64 B, double-buffered: stage s + 1 is written while stage s is multiplied): three stages per super-chunk, one
+// barrier each plus one behind the halo write, 96 MFMAs (1,536 matrix-pipe cycles) and 26 fragment reads per wave and stage.
+// The unpadded 64-B weight rows keep the two buffers within 2 workgroups per CU; slot kg of row R sits at kg ^ ((R >> 1) & 3),
+// which spreads the 16 rows x 4 k-groups of a fragment read (and the 8 rows of a staging write) over all banks.  Every wave owns 32 output channels x 8 image rows (2 x 16 accumulator tiles of 16 x 16): the
+// 6 weight fragments of a stage stay in registers while the 20 pixel fragments (10 halo rows x 2 halves) stream through, each
+// used by up to 3 taps x 2 channel tiles.  Same LDS reads per MAC as the 32x32x16 form, half the accumulator traffic per MAC:
+// under the power cap the chip holds a higher clock (timing-only ablation +9 % on the Co >= 256 layers,
+// profiles/r03_conv_fwd_ab_mfma_shape.txt; MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int TH, int BN, int SC = 1, bool K32 = false>
 struct Cfg {
+    static_assert(!K32 || SC == 2, "K32 stages 32-channel halo tiles");
     static constexpr int WN = BN / 64;
     static constexpr int WM = 4 / WN;
     static_assert(TH / WM == 4, "every wave owns 4 image rows");
@@ -77,17 +89,21 @@ struct Cfg {
     static constexpr int HROWB = NQ * 16 + 16;       // LDS bytes per halo pixel: data + 16 B pad (an odd number of 16-B slots)
     static constexpr int HPASS = 256 / NQ;           // halo rows staged per pass of the 256 threads
     static constexpr int HB = HALO_PIX * HROWB;
-    static constexpr int WB = 9 * BN * ROWB;
+    static constexpr int WROWB = K32 ? 64 : ROWB;    // LDS bytes per weight row (K32: no pad, the 16-B slots of a row are swizzled)
+    static constexpr int WSTG = 3 * BN * 64;         // K32: bytes of one stage's weights; two buffers
+    static constexpr int WB = K32 ? 2 * WSTG : 9 * BN * ROWB;
     static constexpr int P = TH * 32;
     static constexpr int ERS = BN * 2 + 16;          // epilogue LDS row stride (bytes)
     static constexpr int EB = P * ERS;
     static constexpr int SMEM = (HB + WB) > EB ? (HB + WB) : EB;
     static constexpr int KPH = (HALO_PIX + HPASS - 1) / HPASS;   // 16-B halo pieces per thread and super-chunk
-    static constexpr int NPW = 9 * BN * 2;           // 16-B pieces of the weights per chunk
+    static constexpr int NPW = K32 ? 3 * BN * 4 : 9 * BN * 2;   // 16-B pieces of the weights per chunk (K32: per stage)
     static constexpr int KPW = (NPW + 255) / 256;
     static constexpr int TSTEP = 128 / BN;           // taps advanced per weight piece (1 or 2)
     // BN = 64: the last piece (k = 4) is tap 8 for the lower 64 staging rows and does not exist for the upper 64
-    static constexpr bool W_LAST_PARTIAL = (KPW - 1) * TSTEP + (TSTEP - 1) >= 9;
+    static constexpr bool W_LAST_PARTIAL = !K32 && (KPW - 1) * TSTEP + (TSTEP - 1) >= 9;
+    static constexpr int WCO = BN / 32, WRW = 4 / WCO;          // K32: waves over channel groups of 32 x row groups of 8
+    static_assert(!K32 || TH == 8 * WRW, "K32: every wave owns 8 image rows");
     static constexpr int PRE = SC == 2 ? 6 : 8;      // fragment reads issued ahead of the MFMA phase's first MFMA (fewer where registers are short)
 };
 
@@ -109,12 +125,12 @@ __device__ __forceinline__ void* umi_uniform_ptr(const void* p) {
 // one work item = (pixel tile, output-channel block)
 struct Tile { int n, ty0, tx0, c0, cvalid, pt; };
 
-template <int TH, int BN, int SC, bool HAS_TX, int EPI>
+template <int TH, int BN, int SC, bool K32, bool HAS_TX, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx, const half_t* __restrict__ wp8,
     half_t* __restrict__ y, int ldy, float* __restrict__ part, int N, int H, int W, int Ci, int Co, int tiles_x,
     int tiles_y, int n_co, int xcd_chunk, BnRed bn) {
-    using C = Cfg<TH, BN, SC>;
+    using C = Cfg<TH, BN, SC, K32>;
     constexpr int HROWB = C::HROWB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::SMEM];
     // consumer-transform rows of the current / next chunk (16 channels x float4), refilled two chunks ahead so the
@@ -155,6 +171,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int b_base = ((wm * 4) * HALO_W + lrow) * HROWB + lhalf * 16;              // + ((nt+dy)*34 + dx)*HROWB + sub*32
     const int a_base = C::HB + (wn * 64 + lrow) * ROWB + lhalf * 16;                 // + (tap*BN + mt*32)*48
+    // K32: wave = (channel group wc of 32, row group wr of 8); lane = (row / pixel l16 of a 16 x 16 tile, 8-channel group lg)
+    const int wc = wave % C::WCO, wr = wave / C::WCO;
+    const int l16 = lane & 15, lg = lane >> 4;
+    const int bk_base = ((wr * 8) * HALO_W + l16) * HROWB + lg * 16;                 // + (hr*34 + half*16 + dx) * HROWB
+    const int ak_base = C::HB + (wc * 32 + l16) * C::WROWB + ((lg ^ ((l16 >> 1) & 3)) * 16);   // + buffer + (dy*BN + ct*16) * WROWB
+    // K32 weight staging: piece k of a stage = row R = wk_row + 64k of the [3 dy][BN] rows, 8-channel group wk_q
+    const int wkl_base = C::HB + (((tid >> 5) << 3) | (tid & 7)) * C::WROWB + ((((tid >> 3) & 3) ^ ((tid >> 1) & 3)) * 16);   // + buffer + k * 64 * WROWB
+    const int wdy_s = __builtin_amdgcn_readfirstlane(3 * Ci8 * Co * 16);             // bytes from tap (dy, dx) to (dy + 1, dx)
     const int nchunks = Ci >> 4;
     // (Rotating the chunk order per workgroup to spread the weight reads over L2 channels was measured and is
     //  SLOWER: -12 % on 1024->1024; simultaneous readers of one panel share L2 lines.)
@@ -218,6 +242,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         const bool wok = wcol < (t_).cvalid;       /* weight rows past Co read as zeros */                            \
         wbase_v = wok ? wbase : WBAD;                                                                                 \
         wbase_l = (wok && w_last_ok) ? wbase : WBAD;                                                                  \
+        if constexpr (K32) {       /* rows wk_row (and wk_row + 64 for BN = 128) of the tile's channels, k-group wk_q */ \
+            const int wrow_ = ((tid_ >> 5) << 3) | (tid_ & 7), wq_ = (tid_ >> 3) & 3;                                 \
+            const unsigned wb_ = (unsigned)((wq_ * Co + wrow_) * 16);                                                 \
+            wbase_v = wrow_ < (t_).cvalid ? wb_ : WBAD;                                                               \
+            wbase_l = wrow_ + 64 < (t_).cvalid ? wb_ + 64 * 16 : WBAD;                                                \
+        }                                                                                                             \
     } while (0)
     // the zero-padding slots of the halo tile are written here, once per tile, and never by the chunk loop
 #define UMI_ZERO_PADDING()                                                                                             \
@@ -249,6 +279,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                 wrs, (C::W_LAST_PARTIAL && k == C::KPW - 1) ? wbase_l : wbase_v, (c_) * 2 * Co * 16 + k * wstep_s, 0)); \
     } while (0)
 
+    // K32: the weights of stage (super-chunk sc_, tap column dx_): taps (dy, dx_), channels 32 sc_ .. + 31
+#define UMI_ISSUE_WK(sc_, dx_)                                                                                    \
+    do {                                                                                                          \
+        const int ws_ = (((dx_) * Ci8 + 4 * (sc_)) * Co) * 16;                                                    \
+        _Pragma("unroll") for (int k = 0; k < C::KPW; ++k)                                                        \
+            wraw[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(                            \
+                wrs, (BN == 128 && (k & 1)) ? wbase_l : wbase_v, ws_ + (BN == 128 ? k >> 1 : k) * wdy_s, 0));     \
+    } while (0)
+
     // the transform rows are carried by the whole of wave 0 (4 lanes per row, same value): a scalar branch, no exec-mask
     // juggling in the loop.  txbuf[c & 1] holds the rows of chunk c, txr those of chunk c + 2 (indices wrap: the surplus loads
     // of the last two chunks read rows that exist).
@@ -266,7 +305,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
     const Tile cur = decode(blockIdx.x);
     UMI_PLAN(cur);
     UMI_ISSUE_H(0);                     // first: the prologue's one global round trip covers the transform rows as well
-    UMI_ISSUE_W(0);
+    half8 wraw1[K32 ? C::KPW : 1];      // K32: the second stage's weights, in flight with the first's through the prologue only
+    if constexpr (K32) {
+        UMI_ISSUE_WK(0, 0);
+#pragma unroll
+        for (int k = 0; k < C::KPW; ++k)
+            wraw1[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, (BN == 128 && (k & 1)) ? wbase_l : wbase_v, Ci8 * Co * 16 + (BN == 128 ? k >> 1 : k) * wdy_s, 0));
+    } else UMI_ISSUE_W(0);
     UMI_ZERO_PADDING();
     if (HAS_TX) {
         if (tx_wave) {
@@ -278,17 +324,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         __syncthreads();
     }
     {
-        floatx16 acc[2][4];
+        typedef float floatx4 __attribute__((ext_vector_type(4)));
+        floatx16 acc[2][4];                 // 32x32x16 form: [channel tile of 32][image row]
+        floatx4 acck[2][16];                // K32 (16x16x32) form: [channel tile of 16][image row * 2 + half row]
+        if constexpr (K32) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < 16; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) acck[a][b][r] = 0.f;
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        }
 #ifdef UMI_STAMP
         UMI_T(t_loop);
         if (n_chunks_done == 0) t_pro = t_loop - t_start;
 #endif
+        if constexpr (!K32) {
         for (int ci_ = 0; ci_ < nchunks; ++ci_) {
             const int sci = ci_ / SC, sub = ci_ % SC;              // super-chunk, 16-channel chunk inside it
             const bool first = SC == 1 || sub == 0;                // this iteration stages a halo tile
@@ -354,13 +412,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                 }
             }
             // issue order of the phase's 36 fragment reads and 72 MFMAs: PRE reads up front, then one read behind every MFMA pair
+            constexpr int MPR = 2;
             __builtin_amdgcn_sched_group_barrier(0x100, C::PRE, 0);
 #pragma unroll
             for (int i_ = 0; i_ < 36 - C::PRE; ++i_) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 72 - 2 * (36 - C::PRE), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 36 * MPR - MPR * (36 - C::PRE), 0);
             __builtin_amdgcn_s_setprio(0);
 #ifdef UMI_STAMP
             UMI_T(t3);
@@ -372,6 +431,109 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             ++n_chunks_done;
 #endif
         }
+        } else {
+        // ---- K32: three tap-column stages per 32-channel super-chunk -------------------------------------------------------
+        // Invariant at the top of stage st: weight buffer st & 1 holds stage st (written one stage earlier, behind a barrier), the
+        // registers hold stage st + 1, which is written into the other buffer now -- every wave left that buffer at the barrier
+        // that ended stage st - 1 -- and stage st + 2 is requested.  The halo tile has one buffer: it is written at the top of a
+        // super-chunk's first stage, with a barrier of its own in front of the fragment reads.
+#pragma unroll
+        for (int k = 0; k < C::KPW; ++k) *reinterpret_cast<half8*>(smem + wkl_base + k * 64 * C::WROWB) = wraw[k];
+#pragma unroll
+        for (int k = 0; k < C::KPW; ++k) wraw[k] = wraw1[k];
+        int sci = 0, dx = 0, wcur = 0;                             // wcur: byte offset of the weight buffer this stage reads
+        const int nst = 3 * nsc;
+        for (int st = 0; st < nst; ++st) {
+            const bool first = dx == 0;                            // this stage also stages the super-chunk's halo tile
+#ifdef UMI_STAMP
+            UMI_T(t0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            UMI_T(t0b);
+#endif
+            if (first) {
+                if (HAS_TX) {
+                    float4 t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = txbuf[sci & 1][j * C::NQ + hq];
+#pragma unroll
+                    for (int k = 0; k < C::KPH; ++k) hraw[k] = umi_tx8(hraw[k], t);
+                }
+#pragma unroll
+                for (int k = 0; k < C::KPH; ++k)
+                    *reinterpret_cast<half8*>(smem + (k == C::KPH - 1 ? hl_last : (hoff[k] != OOB ? hl_a : hl_b) + k * C::HPASS * HROWB)) = hraw[k];
+            }
+            if (st + 1 < nst) {
+#pragma unroll
+                for (int k = 0; k < C::KPW; ++k)
+                    *reinterpret_cast<half8*>(smem + wkl_base + (C::WSTG - wcur) + k * 64 * C::WROWB) = wraw[k];
+            }
+#ifdef UMI_STAMP
+            UMI_T(t1);
+#endif
+            if (first) __syncthreads();
+#ifdef UMI_STAMP
+            UMI_T(t2);
+#endif
+            if (first) {
+                if (HAS_TX && tx_wave) {
+                    txbuf[sci & 1][txs] = txr;          // every thread is past its reads of this buffer (barrier above)
+                    txc = txc + 1 < nsc ? txc + 1 : 0;
+                    txr = UMI_TX_ROWS(txc);
+                }
+                if (sci + 1 < nsc) UMI_ISSUE_H(sci + 1);   // in flight for three MFMA phases
+            }
+            {
+                const int ndx = dx == 0 ? 2 : dx - 1, nsci = dx == 0 ? sci : sci + 1;      // stage st + 2
+                if (st + 2 < nst) UMI_ISSUE_WK(nsci, ndx);
+            }
+            __builtin_amdgcn_s_setprio(3);
+            {
+                half8 af[3][2];
+                const unsigned char* ap = smem + ak_base + wcur;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        af[dy][ct] = *reinterpret_cast<const half8*>(ap + (dy * BN + ct * 16) * C::WROWB);
+                const unsigned char* bp = smem + bk_base + dx * HROWB;
+#pragma unroll
+                for (int hr = 0; hr < 10; ++hr)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const half8 bf = *reinterpret_cast<const half8*>(bp + (hr * HALO_W + h * 16) * HROWB);
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int r = hr - dy;
+                            if (r >= 0 && r < 8) {
+#pragma unroll
+                                for (int ct = 0; ct < 2; ++ct)
+                                    acck[ct][r * 2 + h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[dy][ct], bf, acck[ct][r * 2 + h], 0, 0, 0);
+                            }
+                        }
+                    }
+            }
+            // issue order: the 6 weight fragments and the first 4 pixel fragments up front, then one pixel fragment behind every
+            // (halo row, half) group of MFMAs -- four groups (>= 8 MFMAs) ahead of its use
+#define UMI_G(n_) __builtin_amdgcn_sched_group_barrier(0x008, n_, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+            UMI_G(2); UMI_G(2); UMI_G(4); UMI_G(4);
+            UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#undef UMI_G
+            __builtin_amdgcn_s_setprio(0);
+#ifdef UMI_STAMP
+            UMI_T(t3);
+#endif
+            __syncthreads();
+#ifdef UMI_STAMP
+            UMI_T(t4);
+            seg[0] += t0b - t0; seg[1] += t1 - t0b; seg[2] += t2 - t1; seg[3] += t3 - t2; seg[4] += t4 - t3;
+            ++n_chunks_done;
+#endif
+            wcur = C::WSTG - wcur;
+            if (++dx == 3) { dx = 0; ++sci; }
+        }
+        }
 #ifdef UMI_STAMP
         UMI_T(t_ep0);
 #endif
@@ -380,6 +542,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         // EPI 3 (inference): this conv's own BatchNorm (running statistics) + ReLU applied here, on the fp32 accumulators, so the
         // tensor is stored ACTIVATED and its consumers load it as it is (no statistics, no transform on load)
         const int n = cur.n, ty0 = cur.ty0, tx0 = cur.tx0, c0 = cur.c0, cvalid = cur.cvalid, pt = cur.pt;
+        if constexpr (K32) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int co = wc * 32 + ct * 16 + lg * 4;          // accumulator rows = 4 consecutive channels per lane
+                float4 ot[4];
+                if (EPI == 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        ot[j] = co + j < cvalid ? bn.tx[c0 + co + j] : make_float4(0.f, 1.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int pt_ = 0; pt_ < 16; ++pt_) {
+                    const int pix = (wr * 8 + (pt_ >> 1)) * 32 + (pt_ & 1) * 16 + l16;
+                    half4 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acck[ct][pt_][j];
+                        if (EPI == 3) v = umi_tx(v, ot[j]);
+                        h[j] = (half_t)v;
+                    }
+                    *reinterpret_cast<half4*>(smem + pix * C::ERS + co * 2) = h;
+                }
+            }
+        } else
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -544,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #endif
 }
 
-template <int TH, int BN, int SC>
+template <int TH, int BN, int SC, bool K32 = false>
 int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int ldy, float* part, int N, int H, int W,
            int Ci, int Co, const BnRed* bnred, hipStream_t s, const void* out_tx = nullptr) {
     const int tiles_x = (W + 31) / 32, tiles_y = (H + TH - 1) / TH, n_co = (Co + BN - 1) / BN;
@@ -555,7 +741,7 @@ int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int
     const int xcd_chunk = (n_co > 1 && !xcd_off) ? (int)(nblk / 8) : 0;     // ids beyond 8 * chunk (the remainder) keep their order
     const BnRed bn = bnred ? *bnred : BnRed{nullptr, 0, (const float4*)out_tx, nullptr};
 #define GO(HT, EP)                                                                                               \
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, SC, HT, EP>), grid, block, 0, s, (const half_t*)x, ldx, \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, SC, K32, HT, EP>), grid, block, 0, s, (const half_t*)x, ldx, \
                        (const float4*)tx, (const half_t*)wp8, (half_t*)y, ldy, part, N, H, W, Ci, Co, tiles_x,   \
                        tiles_y, n_co, xcd_chunk, bn)
     if (out_tx) { if (tx) GO(true, 3); else GO(false, 3); }
@@ -570,6 +756,7 @@ int launch(const void* x, int ldx, const void* tx, const void* wp8, void* y, int
 #undef UMI_ISSUE_H
 #undef UMI_TX_ROWS
 #undef UMI_ISSUE_W
+#undef UMI_ISSUE_WK
 #undef UMI_PLAN
 #undef UMI_ZERO_PADDING
 }  // namespace
@@ -611,7 +798,9 @@ int umi_conv3x3_mfma_stat_rows(int N, int H, int W, int Ci, int Co, int ldx) {
 
 #define UMI_GO(...)                                                                          \
     do {                                                                                     \
+        if (use_bn128(Co) && Ci % 32 == 0 && g_impl != 2) return launch<8, 128, 2, true>(__VA_ARGS__); \
         if (use_bn128(Co)) return launch<8, 128, 1>(__VA_ARGS__);                            \
+        if (Ci % 32 == 0 && g_impl == 3) return launch<16, 64, 2, true>(__VA_ARGS__);        \
         if (Ci % 32 == 0 && g_impl != 2) return launch<16, 64, 2>(__VA_ARGS__);              \
         return launch<16, 64, 1>(__VA_ARGS__);                                               \
     } while (0)
