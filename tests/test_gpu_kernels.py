@@ -42,6 +42,9 @@ CASES = [  # N, H, W, Ci, Co, ldx_extra, ldy_extra, use_tx
     (2, 20, 45, 64, 16, 0, 0, True),       # Co = 16: partial output-channel tile (TransUNet decoder tail)
     (2, 19, 33, 16, 16, 0, 16, True),      # Ci = Co = 16 into a channel slice
     (1, 16, 40, 32, 200, 0, 0, False),     # 128 + 72 output channels
+    (2, 20, 45, 96, 128, 0, 0, True),      # 16x16x32 form (Co % 128 == 0, Ci % 32 == 0): 3 super-chunks, ragged tiles
+    (1, 9, 33, 64, 256, 32, 64, False),    # same form, no transform, channel-slice views on both sides
+    (1, 8, 32, 32, 128, 0, 0, True),       # same form, ONE super-chunk (the prologue's two weight stages + one more)
 ]
 
 
