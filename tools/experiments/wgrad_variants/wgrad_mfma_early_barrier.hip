@@ -330,8 +330,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
         // Images made of whole tiles (W % 32 == 0, H % TR == 0: every shipped config): only the outermost halo ring of an edge tile
         // can leave the image, so a piece's validity is (its ring bits) & (the tile's edge bits) -- one v_and per piece and
         // tile instead of two coordinate additions and four comparisons, and the tile origin rides in the scalar offset of the
-        // loads.  The producers share their SIMD's issue port with the MFMA wave: ~55 fewer vector instructions per tile, -0.9 %
-        // on the bench's 17 layers (tools/ab_wgrad.py, same box).
+        // loads.  The producers share their SIMD's issue port with the MFMA wave: ~55 fewer vector instructions per tile.
         // (The per-lane offset of a buffer load is range-checked on its own and must not be negative: the halo ring's row -1 /
         //  column -1 are, relative to the tile origin, so the resource starts `aback` bytes in front of the image and every
         //  per-lane offset carries +aback.)
@@ -542,6 +541,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
     __syncthreads();                                        // tile 0 staged
 #define UMI_LD_A16(dst, ca_, dx_)                                                                                \
     _Pragma("unroll") for (int rr = 0; rr < TR + 2; ++rr) dst[rr] = tr_frag(a_frag + (rr * 34 + (dx_)) * PROW + (ca_) * 32)
+#define UMI_LD_A16P(dst, ca_, dx_, r0_, r1_)                                                                     \
+    _Pragma("unroll") for (int rr = r0_; rr < r1_; ++rr) dst[rr] = tr_frag(a_frag + (rr * 34 + (dx_)) * PROW + (ca_) * 32)
 #define UMI_MMA16(af_, ca_, dx_)                                                                                 \
     _Pragma("unroll") for (int r = 0; r < TR; ++r)                                                              \
         _Pragma("unroll") for (int dyi = 0; dyi < 3; ++dyi)                                                     \
@@ -551,55 +552,65 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_ws_kernel(
 #ifdef UMI_STAMP
     unsigned long long cw = 0, cb_ = 0, cstart = 0;
 #endif
-    for (int i = 0; i < ntile; ++i) {
-#ifdef UMI_STAMP
-        UMI_TW(c0);
-#endif
-        const unsigned char* a_frag = smem_ws + (i & 1) * SMEM + wci * A_CHUNK + frag_lane;
-        const unsigned char* b_frag = smem_ws + (i & 1) * SMEM + A_BYTES + wco * B_CHUNK + frag_lane;
-        half8 a0[TR + 2], a1[TR + 2], bfr[TR][2];
-#pragma unroll
-        for (int r = 0; r < TR; ++r)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) bfr[r][cb] = tr_frag(b_frag + (r * 32) * PROW + cb * 32);
-#ifndef UMI_WS_COARSE
-        // the 12 transposing reads of step s + 1 are spread between the 24 MFMAs of step s (one read behind every MFMA pair) instead of
-        // issued as a burst in front of them: -1.5 % on the 17 layers of the bench (round 3, tools/ab_wgrad.py; UMI_WS_COARSE = the old order)
-#define UMI_STEP(ld_, mma_) do { ld_; mma_;                                                              \
-            _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                     \
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }  \
+    // One tile = 6 steps (input-channel tile ca x tap column dx) of 24 MFMAs; the 12 transposing reads of step s + 1 are spread
+    // between the MFMAs of step s (one read behind every MFMA pair; -1.5 % against a burst in front of them).
+    // The tile's barrier sits in front of its LAST step, behind this wave's last read of the tile: the producers, who arrive there
+    // with the next tile stored, may then overwrite this one, and the last step's MFMAs cover the reads of the next tile's first six
+    // x fragments.  The next tile then starts with the dY fragments of its rows 0-1 only (8 reads) in front of its first MFMA
+    // and takes rows 2-3 under way (in-kernel stamps before: ~525 of a tile's ~3,400 consumer cycles between the barrier and
+    // the first MFMA, 28 reads in front of it).
+#define UMI_STEP(ld_, mma_) do { ld_; mma_;                                                                      \
+            _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
             UMI_PIN(); } while (0)
-        UMI_LD_A16(a0, 0, 0); UMI_PIN();
-        UMI_STEP(UMI_LD_A16(a1, 1, 0), UMI_MMA16(a0, 0, 0));
-        UMI_STEP(UMI_LD_A16(a0, 0, 1), UMI_MMA16(a1, 1, 0));
-        UMI_STEP(UMI_LD_A16(a1, 1, 1), UMI_MMA16(a0, 0, 1));
-        UMI_STEP(UMI_LD_A16(a0, 0, 2), UMI_MMA16(a1, 1, 1));
-        UMI_STEP(UMI_LD_A16(a1, 1, 2), UMI_MMA16(a0, 0, 2));
-        UMI_MMA16(a1, 1, 2);
-#undef UMI_STEP
-#else
-        UMI_LD_A16(a0, 0, 0); UMI_PIN();
-#ifdef UMI_STAMP_STEPS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        UMI_TW(cs0);
-        cstart += cs0 - c0;
-#endif
-        UMI_LD_A16(a1, 1, 0); UMI_PIN(); UMI_MMA16(a0, 0, 0); UMI_PIN();
-        UMI_LD_A16(a0, 0, 1); UMI_PIN(); UMI_MMA16(a1, 1, 0); UMI_PIN();
-        UMI_LD_A16(a1, 1, 1); UMI_PIN(); UMI_MMA16(a0, 0, 1); UMI_PIN();
-        UMI_LD_A16(a0, 0, 2); UMI_PIN(); UMI_MMA16(a1, 1, 1); UMI_PIN();
-        UMI_LD_A16(a1, 1, 2); UMI_PIN(); UMI_MMA16(a0, 0, 2); UMI_PIN();
-        UMI_MMA16(a1, 1, 2);
-#endif
+    // (first step: 16 dY reads + 12 x reads; 8 in front, two behind every MFMA pair after that)
+#define UMI_STEP0(ld_, mma_) do { ld_; mma_;                                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);                                                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } \
+            UMI_PIN(); } while (0)
+#define UMI_LD_BALL(bf_)                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < TR; ++r)                                                              \
+        _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) bfr[r][cb] = tr_frag((bf_) + (r * 32) * PROW + cb * 32)
+    {
+        half8 a0[TR + 2], a1[TR + 2], bfr[TR][2];
+        if (ntile > 0) {
+            const unsigned char* a_frag = smem_ws + wci * A_CHUNK + frag_lane;
+            UMI_LD_A16P(a0, 0, 0, 0, 3);
+            UMI_PIN();
+        }
+        for (int i = 0; i < ntile; ++i) {
 #ifdef UMI_STAMP
-        UMI_TW(c1);
+            UMI_TW(c0);
 #endif
-        __syncthreads();
+            const unsigned char* a_frag = smem_ws + (i & 1) * SMEM + wci * A_CHUNK + frag_lane;
+            const unsigned char* b_frag = smem_ws + (i & 1) * SMEM + A_BYTES + wco * B_CHUNK + frag_lane;
+            UMI_STEP0(UMI_LD_BALL(b_frag); UMI_LD_A16P(a0, 0, 0, 3, 6); UMI_LD_A16(a1, 1, 0), UMI_MMA16(a0, 0, 0));
+            UMI_STEP(UMI_LD_A16(a0, 0, 1), UMI_MMA16(a1, 1, 0));
+            UMI_STEP(UMI_LD_A16(a1, 1, 1), UMI_MMA16(a0, 0, 1));
+            UMI_STEP(UMI_LD_A16(a0, 0, 2), UMI_MMA16(a1, 1, 1));
+            UMI_STEP(UMI_LD_A16(a1, 1, 2), UMI_MMA16(a0, 0, 2));
 #ifdef UMI_STAMP
-        UMI_TW(c2);
-        cw += c1 - c0; cb_ += c2 - c1;
+            UMI_TW(c1);
 #endif
+            __syncthreads();
+#ifdef UMI_STAMP
+            UMI_TW(c2);
+            cw += c1 - c0; cb_ += c2 - c1;
+#endif
+            if (i + 1 < ntile) {
+                const unsigned char* a_frag = smem_ws + ((i + 1) & 1) * SMEM + wci * A_CHUNK + frag_lane;
+                UMI_MMA16(a1, 1, 2); UMI_LD_A16P(a0, 0, 0, 0, 3);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); UMI_PIN();
+            } else {
+                UMI_MMA16(a1, 1, 2);
+            }
+        }
     }
+#undef UMI_STEP
+#undef UMI_STEP0
+#undef UMI_LD_BALL
 #ifdef UMI_STAMP
     {
         const int bid = blockIdx.y * gridDim.x + blockIdx.x;
