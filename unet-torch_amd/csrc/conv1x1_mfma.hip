@@ -470,7 +470,9 @@ int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, co
     // largest tile that still gives every CU two workgroups; small GEMMs (ViT linears: 4,704 tokens x 768) take
     // 128-pixel tiles, and 64-channel ones if that is still not enough
     const bool bn128 = Ntot % 128 == 0;
-    const long want = 400;                                  // ~0.8 of the 512 resident workgroup slots
+    // ~0.6 of the 512 resident workgroup slots.  (400 sent the ViT's Q/K/V linear -- 4,704 x 768 -> 2,304: 342 tiles of 256 x 128 --
+    // to 256 x 64 tiles: 35.2 us against 29.0, tools/ab_gemm.py; the other linears' picks are the same with either value.)
+    const long want = 300;
     const long b_256_128 = ((M + 255) / 256) * (Ntot / 128), b_128_128 = ((M + 127) / 128) * (Ntot / 128);
     const long b_256_64 = ((M + 255) / 256) * (Ntot / 64);
     geo.accum = (flags & UMI_CONV_ACCUMULATE) ? 1 : 0;
