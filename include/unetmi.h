@@ -49,9 +49,12 @@ enum { UMI_CONV_UPSAMPLE2 = 1,   /* ConvTranspose2d(k=2,s=2): tap t=(dy,dx) scat
 int umi_version(void);
 const char* umi_arch(void);          /* "gfx950" */
 
-/* Experiment knob (process-wide) for same-process A/B timing of variants of csrc/conv_mfma.hip (tools/ab_conv.py with libraries
- * from tools/build_variant.py): the shipped library has one conv3x3 matrix-core kernel and ignores the value.  Returns the
- * previous value; values outside 1..8 only query.  Initial value: 1 or env UMI_CONV3X3_IMPL. */
+/* Knob (process-wide) for same-process A/B timing of the conv3x3 matrix-core kernel's forms (csrc/conv_mfma.hip, tools/ab_conv.py):
+ *   1 (default)  v_mfma_f32_16x16x32_f16 form where Co % 128 == 0 and Ci % 32 == 0, the 32x32x16 form elsewhere;
+ *   2            the 32x32x16 form everywhere (the arithmetic order of rounds 1-2);
+ *   3            the 16x16x32 form on the 64-output-channel tiles too (Ci % 32 == 0).
+ * The forms differ by fp32 summation order only (<= 1 fp16 ulp on ~0.2 % of the outputs).  Returns the previous value; values
+ * outside 1..8 only query.  Initial value: 1 or env UMI_CONV3X3_IMPL. */
 int umi_tune_conv3x3_impl(int impl);
 
 /* Re-layout of a weight tensor into the kernels' [T][K][N] packing (dtype storage):
