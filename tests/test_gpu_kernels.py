@@ -128,7 +128,8 @@ def test_wgrad_fast_path_vs_reference_and_generic(shape):
     assert (res["fast"] - ref).abs().max().item() < 6e-3 * scale
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 6, 128, 64), (1, 16, 16, 64, 128), (2, 9, 7, 256, 128)])
+@pytest.mark.parametrize("shape", [(2, 5, 6, 128, 64), (1, 16, 16, 64, 128), (2, 9, 7, 256, 128),
+                                   (1, 80, 81, 128, 256)])       # last: a 6,480-pixel map, 1,024 output columns
 def test_conv_transpose_mfma_fwd_and_dgrad(shape):
     """ConvTranspose2d(k2,s2) forward (scatter epilogue) and its data gradient (space-to-depth gather) on the
     pointwise MFMA kernel vs torch and vs the generic kernels; destination is a padded channel slice."""
@@ -184,6 +185,45 @@ def test_conv1x1_mfma_plain():
     ops.conv_fwd(x.to(DEV), None, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), b.to(DEV), y, 1, 1, 1, 0)
     assert ops.conv_plan(x.to(DEV), y, 1, 1, 1, 0, 0, True)[0] == 1
     assert (y.float().cpu() - ref).abs().max().item() < 3e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [(1, 25, 40, 128, 64, True, True),      # M = 1000 (ragged last tile), 64-column tiles
+                                  (2, 65, 100, 256, 512, True, False),   # M = 13000: 128-column tiles, transform, no bias
+                                  (1, 48, 98, 768, 768, False, True),    # a ViT linear's shape (4704 tokens)
+                                  (1, 7, 9, 384, 192, False, False)])    # one partial tile
+def test_conv1x1_mfma_shapes_and_tile_override(case):
+    """The pointwise MFMA kernel on GEMM-like shapes (ragged pixel count, transform, bias, channel-slice views on both sides) vs torch,
+    and its default tile pick vs a forced tile (two summation-order-identical runs of the same kernel family)."""
+    import os
+    lib, ops = _gpu()
+    N, H, W, Ci, Co, use_tx, use_b = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    xb = torch.randn(N, H, W, Ci + 16, generator=g).half()
+    x = xb[..., 8:8 + Ci]
+    wt = (torch.randn(Co, Ci, 1, 1, generator=g) * (1.0 / Ci) ** 0.5).half().float()
+    b = 0.1 * torch.randn(Co, generator=g) if use_b else None
+    t = _tx(Ci, g) if use_tx else None
+    a = _apply_tx(x.float(), t).half().float() if use_tx else x.float()
+    ref = F.conv2d(a.permute(0, 3, 1, 2), wt, b).permute(0, 2, 3, 1)
+    xd = xb.to(DEV)[..., 8:8 + Ci]
+    wd = wt.to(DEV)
+    outs = []
+    for tile in (None, "256x64"):
+        if tile:
+            os.environ["UMI_C1_TILE"] = tile
+        try:
+            yb = torch.full((N, H, W, Co + 32), 3.0, device=DEV, dtype=torch.float16)
+            y = yb[..., 16:16 + Co]
+            ops.conv_fwd(xd, t.to(DEV) if use_tx else None, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)),
+                         b.to(DEV) if use_b else None, y, 1, 1, 1, 0)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("UMI_C1_TILE", None)
+        assert (yb[..., :16] == 3.0).all() and (yb[..., 16 + Co:] == 3.0).all()
+        outs.append(y.float().cpu())
+    scale = ref.abs().max().item()
+    assert (outs[0] - ref).abs().max().item() < 3e-3 * scale
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-3 * scale      # two summation orders of the same fp16 operands
 
 
 @pytest.mark.parametrize("cin", [1, 3])
