@@ -830,23 +830,71 @@ struct WgPending { const float* part; float* dW; long s_co, s_ci, s_t; float sca
 static thread_local WgPending* g_wgrad_defer = nullptr;
 void umi_wgrad_defer_set(void* slot) { g_wgrad_defer = (WgPending*)slot; }
 
-void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
-                             long s_t, float scale, hipStream_t st) {
-    if (g_wgrad_defer) {
-        *g_wgrad_defer = WgPending{part, dW, s_co, s_ci, s_t, scale, splits, RS, Ci, Co};
-        g_wgrad_defer = nullptr;
-        return;
+// Transposing form for the large weights (round 3).  The slabs are [tap][ci][co] (co fastest), the parameter is OIHW (or IOHW for
+// ConvTranspose2d): written element by element the outputs of a workgroup are 4-byte stores a whole row apart -- 31 M of them per
+// U-Net step, partial lines that leave L2 before their neighbours arrive (0.44 ms/step for 0.7 GB = 1.6 TB/s).  Here a workgroup
+// owns a tile of 32 output channels x 8 input channels x all taps, reduces it row by row with the SAME per-element arithmetic
+// (lane l sums splits l, l + 8, ... in two chains, the 8 lane sums added in lane order: bit-identical results), collects the
+// values in LDS in the parameter's order and writes runs of 8 * RS (OIHW) or 32 * RS (IOHW) consecutive floats.
+// Taken where it yields >= 512 tiles (small weights keep the element-wise form: their parallelism is in the split dimension).
+constexpr int WGT_CO = 32, WGT_CI = 8;
+__host__ __device__ inline int wg_tmode(const WgPending& d) {       // 0 = element-wise, 1 = OIHW tiles, 2 = IOHW tiles
+    if (d.Co % WGT_CO || d.Ci % WGT_CI || d.RS > 9 || d.s_t != 1 || (((uintptr_t)d.part) & 15)) return 0;
+    if ((long)(d.Co / WGT_CO) * (d.Ci / WGT_CI) < 512) return 0;
+    if (d.s_ci == d.RS && d.s_co == (long)d.Ci * d.RS) return 1;
+    if (d.s_co == d.RS && d.s_ci == (long)d.Co * d.RS) return 2;
+    return 0;
+}
+__device__ void wg_reduce_tiles(const WgPending& d, int mode, int my_blk, int n_blk) {
+    __shared__ float4 redt[8][33];
+    __shared__ float tile[WGT_CO * WGT_CI * 9 + 64];
+    const int ox = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int RS = d.RS, ncob = d.Co / WGT_CO, ncib = d.Ci / WGT_CI, rows = WGT_CI * RS;
+    const long total4 = (long)RS * d.Ci * d.Co / 4;             // float4 per split slab
+    for (int tl = my_blk; tl < ncob * ncib; tl += n_blk) {
+        const int cob = tl % ncob, cib = tl / ncob;
+        for (int r0 = 0; r0 < rows; r0 += 4) {                  // 4 (tap, ci) rows x 8 float4 of output channels per pass
+            const int row = r0 + (ox >> 3), c4 = ox & 7;
+            const int tap = row / WGT_CI, cil = row - tap * WGT_CI;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (row < rows) {
+                const float4* p = reinterpret_cast<const float4*>(d.part) + (((long)tap * d.Ci + cib * WGT_CI + cil) * d.Co + cob * WGT_CO) / 4 + c4;
+                int z = sl;
+                for (; z + 8 < d.splits; z += 16) {
+                    float4 u = p[(long)z * total4], v = p[(long)(z + 8) * total4];
+                    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+                }
+                if (z < d.splits) { float4 u = p[(long)z * total4]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+                a = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            }
+            redt[sl][ox] = a;
+            __syncthreads();
+            if (sl == 0 && row < rows) {
+                float4 t4 = redt[0][ox];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) { float4 u = redt[k][ox]; t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w; }
+                const float v[4] = {t4.x * d.scale, t4.y * d.scale, t4.z * d.scale, t4.w * d.scale};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int co = c4 * 4 + k;
+                    // OIHW: [co][ci][tap]   IOHW: [ci][co][tap]   (+1 float of padding per outer row against bank conflicts)
+                    const int idx = mode == 1 ? co * (WGT_CI * RS + 1) + cil * RS + tap : cil * (WGT_CO * RS + 1) + co * RS + tap;
+                    tile[idx] = v[k];
+                }
+            }
+            __syncthreads();
+        }
+        // the tile in the parameter's order: runs of consecutive floats
+        const int inner = mode == 1 ? WGT_CI * RS : WGT_CO * RS, outer = mode == 1 ? WGT_CO : WGT_CI;
+        for (int e = threadIdx.x; e < inner * outer; e += 256) {
+            const int o = e / inner, r = e - o * inner;
+            float* dst = mode == 1 ? d.dW + (long)(cob * WGT_CO + o) * d.s_co + (long)(cib * WGT_CI) * d.s_ci + r
+                                   : d.dW + (long)(cib * WGT_CI + o) * d.s_ci + (long)(cob * WGT_CO) * d.s_co + r;
+            *dst = tile[o * (inner + 1) + r];
+        }
+        __syncthreads();
     }
-    if (Co % 4 == 0 && (((uintptr_t)part) & 15) == 0) {
-        long g4 = ((long)RS * Ci * Co / 4 + 31) / 32;
-        if (g4 > 16384) g4 = 16384;
-        hipLaunchKernelGGL(wgrad_reduce_v4_kernel, dim3((unsigned)g4), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
-        return;
-    }
-    long total = (long)RS * Ci * Co;
-    long g = (total + 31) / 32;
-    if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
 }
 
 // up to 16 recorded reductions per launch: blockIdx.y = entry, the block loop and the arithmetic (lane l sums splits l, l+8, ...
@@ -859,6 +907,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgTable t) {
     for (int i = 1; i < 16; ++i) ent += (int)blockIdx.x >= t.blk0[i];
     const WgPending d = t.e[ent];
     const int my_blk = (int)blockIdx.x - t.blk0[ent], n_blk = t.blk0[ent + 1] - t.blk0[ent];
+    if (const int tm = wg_tmode(d)) { wg_reduce_tiles(d, tm, my_blk, n_blk); return; }
     const int ox = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const bool vec = d.Co % 4 == 0 && (((uintptr_t)d.part) & 15) == 0;
     const int W4 = vec ? 4 : 1;
@@ -924,6 +973,7 @@ extern "C" int umi_wgrad_reduce_group(int n, const void* items, umi_stream_t str
             if (!t.e[i].part || !t.e[i].dW || t.e[i].splits <= 0) return UMI_ERR_BADARG;
             const bool vec = t.e[i].Co % 4 == 0 && (((uintptr_t)t.e[i].part) & 15) == 0;
             long g = ((long)t.e[i].RS * t.e[i].Ci * t.e[i].Co / (vec ? 4 : 1) + 31) / 32;
+            if (wg_tmode(t.e[i])) g = (long)(t.e[i].Co / WGT_CO) * (t.e[i].Ci / WGT_CI);
             total_blk += (int)(g > 4096 ? 4096 : g);
         }
         t.blk0[16] = total_blk;
@@ -932,6 +982,38 @@ extern "C" int umi_wgrad_reduce_group(int n, const void* items, umi_stream_t str
     }
     return UMI_OK;
 }
+
+void umi_launch_wgrad_reduce(const float* part, int splits, int RS, int Ci, int Co, float* dW, long s_co, long s_ci,
+                             long s_t, float scale, hipStream_t st) {
+    if (g_wgrad_defer) {
+        *g_wgrad_defer = WgPending{part, dW, s_co, s_ci, s_t, scale, splits, RS, Ci, Co};
+        g_wgrad_defer = nullptr;
+        return;
+    }
+    {
+        const WgPending one{part, dW, s_co, s_ci, s_t, scale, splits, RS, Ci, Co};
+        if (wg_tmode(one)) {                                    // large weight: the transposing tile form (a one-entry group launch)
+            WgTable t;
+            for (int i = 0; i < 16; ++i) { t.e[i] = one; t.blk0[i] = 0; }
+            long g = (long)(Co / WGT_CO) * (Ci / WGT_CI);
+            if (g > 4096) g = 4096;
+            for (int i = 1; i <= 16; ++i) t.blk0[i] = (int)g;
+            hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)g), dim3(256), 0, st, t);
+            return;
+        }
+    }
+    if (Co % 4 == 0 && (((uintptr_t)part) & 15) == 0) {
+        long g4 = ((long)RS * Ci * Co / 4 + 31) / 32;
+        if (g4 > 16384) g4 = 16384;
+        hipLaunchKernelGGL(wgrad_reduce_v4_kernel, dim3((unsigned)g4), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
+        return;
+    }
+    long total = (long)RS * Ci * Co;
+    long g = (total + 31) / 32;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, part, splits, RS, Ci, Co, dW, s_co, s_ci, s_t, scale);
+}
+
 
 static void wgrad_generic_plan(long P, int Ci, int Co, int RS, int* splits, long* chunk) {
     long tiles = (long)umi_cdiv(Ci, 64) * umi_cdiv(Co, 64) * RS;
