@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const half_t* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
     // every thread walks a contiguous run of pixels: the (image, row, column) cursor advances without divisions and the
-    // 3x3 input window slides (3*CI new values per pixel instead of 9*CI)
+    // 3x3 input window slides (3*CI new values per pixel instead of 9*CI).  (Dealing the pixels round-robin to the lanes, as the
+    // weight-gradient kernel below does for its loads, makes this kernel SLOWER: 0.21 -> 0.31 ms at the bench shape.)
     const int RUN = STEM_PPB / PL;
     long p = p0 + (long)pl * RUN;
     long pend = p + RUN;
@@ -143,12 +144,13 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const half_t* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
     float4 tc = tx ? tx[ci] : make_float4(0.f, 1.f, 0.f, -INFINITY);
-    // contiguous run of pixels per thread: division-free cursor, sliding 3x3 window of this input channel
-    const int RUN = WG_PPB / PL;
-    long p = p0 + (long)pl * RUN;
-    long pend = p + RUN;
+    // Pixels are dealt to the PL pixel lanes round-robin: per trip a workgroup reads PL ADJACENT pixels of dy (PL x 128 B contiguous
+    // at Co = 64).  (Round 1 gave every lane its own contiguous run -- a sliding 3x3 window, three input loads per pixel instead
+    // of nine -- which made 32 K concurrent 128-byte streams of the 537 MB gradient tensor: 1.5 TB/s.  The nine input values
+    // per pixel come from a one-channel tensor that lives in the caches.)
+    long p = p0 + pl;
+    long pend = p0 + WG_PPB;
     if (pend > P) pend = P;
-    if (pend > p0 + WG_PPB) pend = p0 + WG_PPB;
     int n = 0, yy = 0, xx = 0;
     if (p < pend) {
         n = (int)(p / ((long)H * W));
@@ -156,40 +158,34 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const half_t* __rest
         yy = r / W;
         xx = r - yy * W;
     }
-    float win[3][3];
-    bool fresh = true;
-    for (; p < pend; ++p) {
+#pragma unroll 4
+    for (; p < pend; p += PL) {
+        const half8 g = *reinterpret_cast<const half8*>(dy + p * lddy + cg * 8);
+        float win[9];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int hi = yy + dy - 1;
+        for (int dy_ = 0; dy_ < 3; ++dy_) {
+            const int hi = yy + dy_ - 1;
             const bool rowok = hi >= 0 && hi < H;
             const half_t* xr = x + ((long)((long)n * H + (rowok ? hi : 0)) * W) * ldx + ci;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                if (!fresh && dx < 2) { win[dy][dx] = win[dy][dx + 1]; continue; }
                 const int wi = xx + dx - 1;
-                float v = 0.f;
-                if (rowok && wi >= 0 && wi < W) {
-                    v = (float)xr[(long)wi * ldx];
-                    if (tx) v = umi_tx(v, tc);
-                }
-                win[dy][dx] = v;
+                const bool ok = rowok && wi >= 0 && wi < W;
+                float v = (float)xr[(long)(ok ? wi : 0) * ldx];
+                if (tx) v = umi_tx(v, tc);
+                win[dy_ * 3 + dx] = ok ? v : 0.f;
             }
         }
-        fresh = false;
-        half8 g = *reinterpret_cast<const half8*>(dy + p * lddy + cg * 8);
         float gf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) gf[j] = (float)g[j];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float v = win[tap / 3][tap % 3];
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[tap][j] = fmaf(v, gf[j], acc[tap][j]);
-        }
-        if (++xx == W) {
-            xx = 0;
-            fresh = true;
+            for (int j = 0; j < 8; ++j) acc[tap][j] = fmaf(win[tap], gf[j], acc[tap][j]);
+        xx += PL;
+        while (xx >= W) {
+            xx -= W;
             if (++yy == H) { yy = 0; ++n; }
         }
     }
