@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const half_t* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
     // every thread walks a contiguous run of pixels: the (image, row, column) cursor advances without divisions and the
-    // 3x3 input window slides (3*CI new values per pixel instead of 9*CI).  (Dealing the pixels round-robin to the lanes, as the
-    // weight-gradient kernel below does for its loads, makes this kernel SLOWER: 0.21 -> 0.31 ms at the bench shape.)
+    // 3x3 input window slides (3*CI new values per pixel instead of 9*CI).  (Measured at the bench shape, 0.21 ms as is: dealing the
+    // pixels round-robin to the lanes, as the weight-gradient kernel below does for its loads, 0.31 ms; runs of 4 pixels per lane
+    // with adjacent runs across lanes 0.29 ms; the 72 weights of a one-channel stem in registers instead of LDS: no change.)
     const int RUN = STEM_PPB / PL;
     long p = p0 + (long)pl * RUN;
     long pend = p + RUN;
