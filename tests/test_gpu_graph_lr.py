@@ -37,3 +37,10 @@ def test_capture_guard_refuses_live_eager_graph():
     AccumulateGrad nodes bound to that step's stream (tools/experiments/exp_graph_accgrad.py reproduces crash and cure).
     GraphedStep(optimizers=[...]) detects it and raises; after the tensor is detached the capture works."""
     _run("guard", "GRAPH_GUARD_OK")
+
+
+def test_trainer_multitask_graph_mode_with_ragged_batches_follows_eager_trainer():
+    """'multi_task' Trainer with graph=True: two heads' losses from the static buffers, a ragged last batch (second capture from
+    epoch 2 on) over 3 epochs and a resumed iter_num feeding the device-side poly block, against the same Trainer run eagerly:
+    losses, iter_num, learning rate and final weights."""
+    _run("trainer_mt", "GRAPHED_TRAINER_MT_OK")

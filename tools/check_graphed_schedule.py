@@ -137,3 +137,41 @@ elif what == "trainer":
         assert files == list(g["files"])
         print("trainer graph=%s ok" % graph, tr.train_loss_list, opt.param_groups[0]["lr"])
     print("GRAPHED_TRAINER_OK")
+
+elif what == "trainer_mt":
+    # the multi-task branch of the graph mode, a ragged last batch (its own capture from the second epoch on)
+    # over 3 epochs, and a resume with iter_num > 0 feeding the device-side poly block -- graph=True must follow graph=False.
+    import tempfile
+    from torch.utils.data import DataLoader
+    from Trainer import Trainer
+    from tools.gen_golden import PairLabels, multitask_trainer_data
+    runs = {}
+    for graph in (False, True):
+        torch.manual_seed(0)
+        m = Model.UNet_multitask(1, 1, 8, False, compute_dtype="fp32")
+        m.load_state_dict(recipe.fill_state_dict(m.state_dict(), seed=22))
+        m.to(DEV)
+        xs, l1, l2 = multitask_trainer_data()
+        loaders = {"train": DataLoader(PairLabels(xs[:5], l1[:5], l2[:5]), batch_size=2, shuffle=False),     # batches of 2, 2, 1
+                   "val": DataLoader(PairLabels(xs[5:], l1[5:], l2[5:]), batch_size=1)}
+        opt = uo.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        with tempfile.TemporaryDirectory() as td:
+            tr = Trainer(m, "multi_task", torch.cuda.FloatTensor, DEV, td, loaders, 2, opt, 25, 3, "mse", "mse",
+                         lr_scheduler=True, graph=graph)
+            tr.iter_num, tr.max_iterations = 4, 20    # a resumed run: the poly rule starts in the middle of its curve
+            tr.train()
+        if graph:
+            assert len(tr._graphs) == 2, ("expected one graph per batch shape (full, ragged)", list(tr._graphs))
+            opt.sync_host()
+        runs[graph] = dict(train=list(tr.train_loss_list), t1=list(tr.train_loss_list_1), t2=list(tr.train_loss_list_2),
+                           val=list(tr.val_loss_list), it=tr.iter_num, lr=opt.param_groups[0]["lr"],
+                           w=torch.cat([p.detach().flatten() for p in m.parameters()]).double().cpu().numpy())
+        print("trainer_mt graph=%s" % graph, runs[graph]["train"], runs[graph]["it"], runs[graph]["lr"])
+    a, b = runs[False], runs[True]
+    for k in ("train", "t1", "t2", "val"):
+        np.testing.assert_allclose(b[k], a[k], rtol=2e-4, atol=2e-5)
+    assert a["it"] == b["it"] == 4 + 9, (a["it"], b["it"])
+    assert abs(a["lr"] - b["lr"]) < 1e-12, (a["lr"], b["lr"])
+    rel = np.linalg.norm(a["w"] - b["w"]) / np.linalg.norm(a["w"])
+    assert rel < 1e-5, rel
+    print("GRAPHED_TRAINER_MT_OK", rel)
