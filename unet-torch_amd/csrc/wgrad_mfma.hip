@@ -651,18 +651,23 @@ __device__ __forceinline__ half8 tr_frag_s2(const unsigned char* p) {      // pi
     return __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool HAS_TX>
+// YH = 64-channel halves of the low-res operand per workgroup (1: 64 x 64 channel tile, 2: 64 x 128).  With 128 of them every staged
+// hi-res pixel (the operand that dominates the staging: 256 pixels x 64 channels per tile) feeds twice as many MFMAs -- 12 staged
+// pieces per 32 MFMAs and thread instead of 10 per 16 (round 3; 8 accumulator tiles = 128 registers per wave).
+template <bool HAS_TX, int YH>
 __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const half_t* __restrict__ y, int ldy, const float4* __restrict__ txy,
     float* __restrict__ part, int N, int h, int w, int Cx, int Cy, int tiles_x, int tiles_y, int tiles_total,
     int tiles_per_split, int n_cy_t) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM2];
-    __shared__ float4 txs[64];
+    constexpr int SMEM_T = 2 * X2_CHUNK + 2 * YH * Y2_CHUNK;
+    constexpr int KPY = KPY2 * YH;                           // piece k: pixel half k & 1... see y_lds
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_T];
+    __shared__ float4 txs[64 * YH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wcx = wave >> 1, wcy = wave & 1;
-    const int cx0 = (blockIdx.x / n_cy_t) * 64, cy0 = (blockIdx.x % n_cy_t) * 64;
+    const int cx0 = (blockIdx.x / n_cy_t) * 64, cy0 = (blockIdx.x % n_cy_t) * (64 * YH);
     if (HAS_TX) {
-        if (tid < 64) txs[(tid & 7) * 8 + (tid >> 3)] = txy[cy0 + tid];      // transposed: see wgrad3x3
+        if (tid < 64 * YH) txs[(tid >> 6) * 64 + (tid & 7) * 8 + ((tid & 63) >> 3)] = txy[cy0 + tid];      // transposed per half: see wgrad3x3
         __syncthreads();
     }
     const int t_begin = blockIdx.y * tiles_per_split;
@@ -672,17 +677,19 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
 
     const int sub = tid & 7;
     const int x_lds = (sub >> 2) * X2_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;                  // + k*32*PROW
-    const int y_lds = 2 * X2_CHUNK + (sub >> 2) * Y2_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;   // + k*32*PROW
+    const int y_lds = 2 * X2_CHUNK + (sub >> 2) * Y2_CHUNK + (tid >> 3) * PROW + (sub & 3) * 16;   // + (k % KPY2)*32*PROW + (k / KPY2) * 2 * Y2_CHUNK
     const half_t* xin = x + cx0 + sub * 8;
-    const half_t* yin = y + cy0 + sub * 8;
+    const half_t* yin = y + cy0 + sub * 8;                   // + (k / KPY2) * 64 channels
 
-    floatx16 acc[4];
+    floatx16 acc[4][YH];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    half8 xraw[KPX2], yraw[KPY2];
-    bool yvalid[KPY2];
+        for (int b = 0; b < YH; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    half8 xraw[KPX2], yraw[KPY];
+    bool yvalid[KPY];
     half8 zero8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
@@ -699,10 +706,10 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
                           ? *reinterpret_cast<const half8*>(xin + ((long)((long)n_ * H2 + gy) * W2 + gx) * ldx) \
                           : zero8;                                                                              \
         }                                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < KPY2; ++k) {                                                      \
-            int gy = ty0_ + k, gx = tx0_ + (tid >> 3);                                                          \
+        _Pragma("unroll") for (int k = 0; k < KPY; ++k) {                                                       \
+            int gy = ty0_ + (k % KPY2), gx = tx0_ + (tid >> 3);                                                 \
             yvalid[k] = gy < h && gx < w;                                                                       \
-            yraw[k] = yvalid[k] ? *reinterpret_cast<const half8*>(yin + ((long)((long)n_ * h + gy) * w + gx) * ldy) \
+            yraw[k] = yvalid[k] ? *reinterpret_cast<const half8*>(yin + (k / KPY2) * 64 + ((long)((long)n_ * h + gy) * w + gx) * ldy) \
                                 : zero8;                                                                        \
         }                                                                                                       \
     } while (0)
@@ -710,6 +717,7 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
     const int g = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
     const int ch_lane = (16 * (g & 1) + 4 * lp) * 2;
     const unsigned char* x_frag = smem + wcx * X2_CHUNK + 2 * (8 * (g >> 1) + lq) * PROW + ch_lane;
+    // wave wcy multiplies the 32-channel chunk wcy of every 64-channel half: chunk index 2 * half + wcy
     const unsigned char* y_frag = smem + 2 * X2_CHUNK + wcy * Y2_CHUNK + (8 * (g >> 1) + lq) * PROW + ch_lane;
 
     if (t_begin < t_end) UMI_ISSUE2(t_begin);
@@ -717,50 +725,60 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
         if (HAS_TX) {
             int opaque = 0;
             asm volatile("" : "+v"(opaque));
-            float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = txs[j * 8 + sub + opaque];
+            for (int hh = 0; hh < YH; ++hh) {
+                float4 t[8];
 #pragma unroll
-            for (int k = 0; k < KPY2; ++k)
-                if (yvalid[k]) {
-                    yraw[k] = umi_tx8(yraw[k], t);
-                }
+                for (int j = 0; j < 8; ++j) t[j] = txs[hh * 64 + j * 8 + sub + opaque];
+#pragma unroll
+                for (int k = hh * KPY2; k < (hh + 1) * KPY2; ++k)
+                    if (yvalid[k]) {
+                        yraw[k] = umi_tx8(yraw[k], t);
+                    }
+            }
         }
 #pragma unroll
         for (int k = 0; k < KPX2; ++k) *reinterpret_cast<half8*>(smem + x_lds + k * 32 * PROW) = xraw[k];
 #pragma unroll
-        for (int k = 0; k < KPY2; ++k) *reinterpret_cast<half8*>(smem + y_lds + k * 32 * PROW) = yraw[k];
+        for (int k = 0; k < KPY; ++k)
+            *reinterpret_cast<half8*>(smem + y_lds + (k % KPY2) * 32 * PROW + (k / KPY2) * 2 * Y2_CHUNK) = yraw[k];
         __syncthreads();
         if (tile + 1 < t_end) UMI_ISSUE2(tile + 1);
 #pragma unroll
         for (int r = 0; r < T2R; ++r)
 #pragma unroll
             for (int xh = 0; xh < 2; ++xh) {
-                half8 bfr = tr_frag(y_frag + (r * 32 + 16 * xh) * PROW);
+                half8 bfr[YH];
+#pragma unroll
+                for (int hh = 0; hh < YH; ++hh) bfr[hh] = tr_frag(y_frag + hh * 2 * Y2_CHUNK + (r * 32 + 16 * xh) * PROW);
 #pragma unroll
                 for (int tap = 0; tap < 4; ++tap) {
                     half8 afr = tr_frag_s2(x_frag + ((2 * r + (tap >> 1)) * 64 + 32 * xh + (tap & 1)) * PROW);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr, acc[tap], 0, 0, 0);
+#pragma unroll
+                    for (int hh = 0; hh < YH; ++hh) acc[tap][hh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr, bfr[hh], acc[tap][hh], 0, 0, 0);
                 }
             }
         __syncthreads();
     }
 #undef UMI_ISSUE2
-    const int cy = cy0 + wcy * 32 + (lane & 31);
 #pragma unroll
-    for (int tap = 0; tap < 4; ++tap)
+    for (int hh = 0; hh < YH; ++hh) {
+        const int cy = cy0 + hh * 64 + wcy * 32 + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int cx = cx0 + wcx * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            part[(((long)blockIdx.y * 4 + tap) * Cx + cx) * Cy + cy] = acc[tap][r];
-        }
+        for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int cx = cx0 + wcx * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                part[(((long)blockIdx.y * 4 + tap) * Cx + cx) * Cy + cy] = acc[tap][hh][r];
+            }
+    }
 }
 
 void planT(int N, int h, int w, int Cx, int Cy, int* tiles_x, int* tiles_y, int* tiles_total, int* splits, int* tps) {
     *tiles_x = (w + 31) / 32;
     *tiles_y = (h + T2R - 1) / T2R;
     *tiles_total = N * (*tiles_x) * (*tiles_y);
-    const long pairs = (long)(Cx / 64) * (Cy / 64);
+    const long pairs = (long)(Cx / 64) * (Cy % 128 == 0 ? Cy / 128 : Cy / 64);       // workgroup tiles: 64 x 128 channels where Cy allows
     static const long target2 = [] { const char* e = getenv("UMI_WGRAD_SPLIT_TARGET2"); long v = e ? atol(e) : 0; return v > 0 ? v : 1024L; }();
     long want = (target2 + pairs - 1) / pairs;
     const long slab = 4L * Cx * Cy * 4;
@@ -1093,14 +1111,15 @@ int umi_wgradT_mfma(const void* x, int ldx, const void* dy, int lddy, const void
     planT(N, Ho, Wo, Ci, Co, &tiles_x, &tiles_y, &tiles_total, &splits, &tps);
     if (ws_bytes < (size_t)splits * 4 * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
-    const int n_cy_t = Co / 64;
+    const bool wide = Co % 128 == 0;
+    const int n_cy_t = wide ? Co / 128 : Co / 64;
     dim3 grid((Ci / 64) * n_cy_t, splits), block(256);
-    if (txb)
-        hipLaunchKernelGGL(wgradT2x2_mfma_kernel<true>, grid, block, 0, s, (const half_t*)x, ldx, (const half_t*)dy, lddy,
-                           (const float4*)txb, (float*)ws, N, Ho, Wo, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_cy_t);
-    else
-        hipLaunchKernelGGL(wgradT2x2_mfma_kernel<false>, grid, block, 0, s, (const half_t*)x, ldx, (const half_t*)dy, lddy,
-                           (const float4*)txb, (float*)ws, N, Ho, Wo, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_cy_t);
+#define UMI_GO_T(HT, YH_)                                                                                        \
+    hipLaunchKernelGGL((wgradT2x2_mfma_kernel<HT, YH_>), grid, block, 0, s, (const half_t*)x, ldx, (const half_t*)dy, lddy, \
+                       (const float4*)txb, (float*)ws, N, Ho, Wo, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_cy_t)
+    if (txb) { if (wide) UMI_GO_T(true, 2); else UMI_GO_T(true, 1); }
+    else { if (wide) UMI_GO_T(false, 2); else UMI_GO_T(false, 1); }
+#undef UMI_GO_T
     UMI_LAUNCH_CHECK();
     umi_launch_wgrad_reduce((const float*)ws, splits, 4, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
     UMI_LAUNCH_CHECK();
