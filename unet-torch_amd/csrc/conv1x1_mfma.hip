@@ -71,6 +71,8 @@ __device__ __forceinline__ unsigned c1_hash32(unsigned a, unsigned b) {         
 #ifndef UMI_C1_OCC128
 #define UMI_C1_OCC128 4
 #endif
+// (timing-only ablation builds of tools/ab_convT.py -- profiles/r03_convT_trio_per_level.txt -- never compiled into the shipped
+//  library: UMI_X_NOMFMA drops the matrix instructions, UMI_X_NOSTORE the epilogue's global stores)
 #ifdef UMI_X_NOMFMA
 #define UMI_X_MMA(c_, a_, b_) do { if ((ks | ct | i) == 0) c_[0] += (float)a_[0] * (float)b_[0]; } while (0)
 #else
