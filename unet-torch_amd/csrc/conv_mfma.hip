@@ -1,5 +1,12 @@
 // conv3x3 (stride 1, pad 1) forward / dgrad on the gfx950 matrix cores, fp16 storage, fp32 accumulate.
 //
+// TWO FORMS of one kernel template (template parameter K32, picked per shape by UMI_GO at the bottom of this file):
+//   * K32 = true  (Co % 128 == 0 and Ci % 32 == 0; 13 of the U-Net's 17 DoubleConv layers): v_mfma_f32_16x16x32_f16, K = the 32
+//     staged channels of one tap, weights staged per tap column into two swizzled buffers -- described at `struct Cfg`;
+//   * K32 = false (everything else, and UMI_CONV3X3_IMPL=2): the form described next.
+// Shared by both: the staging plan (buffer loads, out-of-range offset = zeros), the consumer-side BatchNorm+ReLU transform,
+// the halo tile in LDS, the epilogue through an LDS tile and the epilogue reductions (EPI).
+//
 // Implicit GEMM, D[co][pixel] += W[co][k] * X[k][pixel] with v_mfma_f32_32x32x16_f16:
 //   * A operand = weights  (M = 32 output channels, K = 16 input channels of one tap)
 //   * B operand = pixels   (N = 32 consecutive pixels of one image row, same K)
