@@ -139,6 +139,14 @@ int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, void* da, in
                          const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
                          int dtype, umi_stream_t stream);
 
+/* The same fusion for the data gradient of the narrow pointwise head (`OutConv`, reference Model.py:89-93; Ci <= 8 logit channels):
+ * da[p][c] = sum_k dl[p][k] * w[k][c] plus part[rows][2][Co], rows = umi_head_dgrad_bnred_rows(...) (0 = shape not taken, call
+ * umi_conv_fwd and umi_bn_bwd_reduce).  wp: the generic [1][Ci][Co] fp16 packing (umi_pack_kn). */
+int umi_head_dgrad_bnred_rows(long P, int Ci, int Co, int ldda, int dtype);
+int umi_head_dgrad_bnred(const void* dl, int lddl, const void* wp, void* da, int ldda, const void* ybn, int ldybn,
+                         const void* txbn, const float* rstd, float* part, long P, int Ci, int Co, int dtype,
+                         umi_stream_t stream);
+
 /* Inference form of Conv2d(3, pad 1, bias=False) -> BatchNorm2d (running statistics) -> ReLU (reference Model.py:15-22 under
  * model.eval(), the evaluation loop test_mc3serousv5.py:877-887): the layer's own transform out_tx[Co] = {mean, scale, shift,
  * lo} is applied to the fp32 accumulators in the epilogue, y = max(scale * conv(tx(x), w) + shift, lo) is stored ACTIVATED

@@ -531,6 +531,40 @@ def test_pool2_bwd_with_bn_reduction_matches_separate_kernels(shape, acc):
     torch.testing.assert_close(sums.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 24, 64, 2), (1, 9, 7, 64, 4), (3, 32, 16, 128, 1), (1, 8, 8, 16, 8)])
+def test_head_dgrad_with_bn_reduction_matches_separate_kernels(shape):
+    """umi_head_dgrad_bnred (OutConv's data gradient + stage 1 of the last DoubleConv's BatchNorm backward) against the narrow
+    pointwise data gradient followed by umi_bn_bwd_reduce: identical gradient tensor, sums equal up to fp32 summation order."""
+    lib, ops = _gpu()
+    N, H, W, C, ncls = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    y = torch.randn(N, H, W, C, generator=g).half().to(DEV)            # the BatchNorm layer's raw output
+    t = _tx(C, g)
+    t[:, 0] = 0.1 * torch.randn(C, generator=g)
+    td = t.to(DEV).contiguous()
+    rstd = (0.5 + torch.rand(C, generator=g)).to(DEV)
+    dl = (torch.randn(N, H, W, ncls, generator=g) * 0.1).half().to(DEV)
+    wo = (torch.randn(ncls, C, 1, 1, generator=g) * 0.2).to(DEV)
+    wp = ops.pack_conv_dgrad(wo, torch.float16, k8=False)
+    da_a = torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+    da_b = torch.empty_like(da_a)
+    ops.conv_fwd(dl, None, lambda lay: ops.pack_conv_dgrad(wo, torch.float16, k8=bool(lay)), None, da_a, 1, 1, 1, 0)
+    part = ops.head_dgrad_bnred(dl, wp, da_b, y, td, rstd)
+    assert part is not None
+    assert torch.equal(da_a, da_b)
+    sums = torch.empty(2, C, dtype=torch.float32, device=DEV)
+    lib.check(lib.fn("umi_bn_bwd_from_partials")(part.data_ptr(), part.numel() // (2 * C), C, sums[0].data_ptr(),
+                                                 sums[1].data_ptr(), ops._stream()), "from_partials")
+    ref = torch.empty(2, C, dtype=torch.float32, device=DEV)
+    M = N * H * W
+    nb = lib.fn("umi_bn_bwd_ws_bytes")(M, C)
+    ws = ops.workspace(nb, y.device)
+    lib.check(lib.fn("umi_bn_bwd_reduce")(da_a.data_ptr(), C, y.data_ptr(), C, td.data_ptr(), rstd.data_ptr(), ref[0].data_ptr(),
+                                          ref[1].data_ptr(), M, C, lib.UMI_F16, ws.data_ptr(), ws.numel(), ops._stream()),
+              "reduce")
+    torch.testing.assert_close(sums.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 64, 64, 64), (1, 13, 37, 72, 136), (3, 8, 32, 128, 64), (1, 5, 70, 16, 24),
                                    (2, 64, 64, 64, 128)])
 @pytest.mark.parametrize("strided", [False, True])

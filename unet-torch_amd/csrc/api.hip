@@ -160,6 +160,26 @@ extern "C" int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, v
     return umi_conv3x3_mfma_bnred(dy, lddy, wp8, da, ldda, ybn, ldybn, txbn, rstd, part, N, H, W, Ci, Co, (hipStream_t)stream);
 }
 
+int umi_smallk_bnred_rows(long P, int Co);
+int umi_smallk_fwd_bnred(const void* x, int ldx, const void* wp, void* y, int ldy, const void* ybn, int ldybn, const void* txbn,
+                         const float* rstd, float* part, long P, int Ci, int Co, hipStream_t s);
+
+// The same fusion for the data gradient of a narrow pointwise conv (the segmentation head `OutConv`, reference Model.py:89-93:
+// Ci <= 8 logit channels -> Co feature channels): da = dl * W^T plus stage 1 of the BatchNorm+ReLU backward of the layer whose
+// activated output feeds the head.  rows = umi_head_dgrad_bnred_rows(P, Co).  wp = the generic [1][Ci][Co] fp16 packing.
+extern "C" int umi_head_dgrad_bnred_rows(long P, int Ci, int Co, int ldda, int dtype) {
+    if (!umi_smallk_fwd_ok(Ci, Co, 1, 1, 1, 0, ldda, dtype, dtype, 0, nullptr, nullptr)) return 0;
+    return umi_smallk_bnred_rows(P, Co);
+}
+extern "C" int umi_head_dgrad_bnred(const void* dl, int lddl, const void* wp, void* da, int ldda, const void* ybn, int ldybn,
+                                    const void* txbn, const float* rstd, float* part, long P, int Ci, int Co, int dtype,
+                                    umi_stream_t stream) {
+    if (!dl || !wp || !da || !ybn || !txbn || !rstd || !part || P <= 0) return UMI_ERR_BADARG;
+    if (!umi_smallk_fwd_ok(Ci, Co, 1, 1, 1, 0, ldda, dtype, dtype, 0, nullptr, nullptr) || ldybn % 8 || ldybn < Co || lddl < Ci)
+        return UMI_ERR_UNSUPPORTED;
+    return umi_smallk_fwd_bnred(dl, lddl, wp, da, ldda, ybn, ldybn, txbn, rstd, part, P, Ci, Co, (hipStream_t)stream);
+}
+
 int umi_conv3x3_mfma_act(const void* x, int ldx, const void* tx, const void* wp8, const void* out_tx, void* y, int ldy, int N,
                          int H, int W, int Ci, int Co, hipStream_t s);
 

@@ -312,6 +312,61 @@ __global__ __launch_bounds__(256) void smallk1x1_fwd_kernel(const half_t* __rest
     }
 }
 
+// The same data gradient + stage 1 of the BatchNorm(+ReLU) backward of the layer whose activated output `da` is the gradient of
+// (ybn / txbn / rstd = that layer's raw output, transform rows and 1/std): part[block][2][C] <- sums of dz and dz * xhat over the
+// block's pixels, dz = stored (rounded) da * [tx(y) > lo] -- what bn_bwd_reduce1_v8 computes in a pass of its own over da and y.
+template <int NC>
+__global__ __launch_bounds__(256) void smallk1x1_bnred_kernel(const half_t* __restrict__ x, int ldx,
+                                                              const half_t* __restrict__ wp, half_t* __restrict__ y,
+                                                              int ldy, const half_t* __restrict__ ybn, int ldybn,
+                                                              const float4* __restrict__ txbn, const float* __restrict__ rstd,
+                                                              float* __restrict__ part, long P, int C) {
+    __shared__ float red[2][256][9];
+    const int G = C >> 3;
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gt % G);                            // (256 % G == 0: the same for every trip of this thread)
+    const long stride_p = ((long)gridDim.x * 256) / G;
+    float w[NC][8];
+    float4 t[8];
+    float rs[8], s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        t[j] = txbn[cg * 8 + j];
+        rs[j] = rstd[cg * 8 + j];
+        s[j] = q[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) w[k][j] = (float)wp[k * C + cg * 8 + j];
+    }
+    for (long p = gt / G; p < P; p += stride_p) {
+        const half8 yv = *reinterpret_cast<const half8*>(ybn + p * ldybn + cg * 8);
+        float d[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) d[k] = (float)x[p * ldx + k];
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) a = fmaf(d[k], w[k][j], a);
+            o[j] = (half_t)a;
+            const float yy = (float)yv[j];
+            const float dz = umi_tx_pre(yy, t[j]) > t[j].w ? (float)o[j] : 0.f;
+            s[j] += dz;
+            q[j] = fmaf(dz, (yy - t[j].x) * rs[j], q[j]);
+        }
+        *reinterpret_cast<half8*>(y + p * ldy + cg * 8) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = s[j]; red[1][threadIdx.x][j] = q[j]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        float a = 0.f;
+        for (int k = 0; k < 256 / G; ++k) a += red[which][k * G + (c >> 3)][c & 7];
+        part[((long)blockIdx.x * 2 + which) * C + c] = a;
+    }
+}
+
 // head weight gradient partials: part[blk][0][c][k] = sum_p tx(x[p][c]) * dl[p][k]   (layout [z][tap=0][ci][co])
 template <int NC>
 __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const half_t* __restrict__ x, int ldx,
@@ -448,6 +503,19 @@ int umi_smallk_fwd(const void* x, int ldx, const void* wp, void* y, int ldy, lon
     if (!al16(y)) return UMI_ERR_BADARG;
     int grid = grid_for(P * (Co / 8));
 #define GO(NC) hipLaunchKernelGGL(smallk1x1_fwd_kernel<NC>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const half_t*)wp, (half_t*)y, ldy, P, Co)
+    switch (Ci) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
+                  case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
+#undef GO
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+
+int umi_smallk_bnred_rows(long P, int Co) { return grid_for(P * (Co / 8)); }
+int umi_smallk_fwd_bnred(const void* x, int ldx, const void* wp, void* y, int ldy, const void* ybn, int ldybn, const void* txbn,
+                         const float* rstd, float* part, long P, int Ci, int Co, hipStream_t s) {
+    if (!al16(y) || !al16(ybn)) return UMI_ERR_BADARG;
+    int grid = grid_for(P * (Co / 8));
+#define GO(NC) hipLaunchKernelGGL(smallk1x1_bnred_kernel<NC>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const half_t*)wp, (half_t*)y, ldy, (const half_t*)ybn, ldybn, (const float4*)txbn, rstd, part, P, Co)
     switch (Ci) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
                   case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
 #undef GO

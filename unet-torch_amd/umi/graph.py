@@ -355,8 +355,17 @@ class Tape:
                 if _wants_grad(a):
                     dx = self.alloc(N, H, W, Ci, device=out.device)
                     wf = weight.detach().float()
-                    ops.conv_fwd(g, None, lambda lay: self._pack("conv_dgrad", weight, wf, bool(lay)), None, dx,
-                                 R, S, 1, R - 1 - pad)
+                    part = None
+                    if ((R, S, pad) == (1, 1, 0) and _fuse_bnred() and os.environ.get("UMI_NO_HEAD_BNRED") != "1" and a.grad is None and a.parts is None and a.bn_rstd is not None
+                            and a.tx is not None and self.dtype == torch.float16 and g.dtype == torch.float16):
+                        # the head's data gradient is the only contribution to the last DoubleConv's gradient: stage 1 of that
+                        # layer's BatchNorm backward rides on it (a pass over 2 x 537 MB at the bench shape otherwise)
+                        part = ops.head_dgrad_bnred(g, self._pack("conv_dgrad", weight, wf, False), dx, a.raw, a.tx, a.bn_rstd)
+                    if part is not None:
+                        a.bn_part, a.bn_part_at = part, a.gives + 1
+                    else:
+                        ops.conv_fwd(g, None, lambda lay: self._pack("conv_dgrad", weight, wf, bool(lay)), None, dx,
+                                     R, S, 1, R - 1 - pad)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o

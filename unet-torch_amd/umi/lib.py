@@ -115,6 +115,9 @@ SIGNATURES = {
                                     c_int, c_int, c_void_p]),
     "umi_conv_dgrad_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_head_dgrad_bnred_rows": (c_int, [c_long, c_int, c_int, c_int, c_int]),
+    "umi_head_dgrad_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_long, c_int, c_int, c_int, c_void_p]),
     "umi_bn_bwd_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "umi_bn_stats_rows": (c_int, [c_long, c_int]),
     "umi_bn_stats": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_void_p]),

@@ -566,6 +566,28 @@ def conv_dgrad_bnred(dy, wp8, da, ybn, txbn, rstd):
     return part
 
 
+def head_dgrad_bnred(dl, wp, da, ybn, txbn, rstd):
+    """Data gradient of a narrow pointwise conv (OutConv: <= 8 logit channels) that also emits stage 1 of the BatchNorm backward
+    reduction of the layer `da` belongs to (umi_head_dgrad_bnred).  Returns the partial-sum tensor, or None when the shape is not
+    taken (nothing was launched).  `wp`: the generic [1][Ci][Co] packing of the transposed weight."""
+    N, H, W, Ci, lddl = _nhwc(dl)
+    _, _, _, Co, ldda = _nhwc(da)
+    ldybn = _nhwc(ybn)[4]
+    P = N * H * W
+    if dl.dtype != torch.float16 or da.dtype != torch.float16 or ybn.dtype != torch.float16:
+        return None
+    rows = L.fn("umi_head_dgrad_bnred_rows")(P, Ci, Co, ldda, _dt(dl))
+    if rows <= 0:
+        return None
+    part = torch.empty(rows * 2 * Co, dtype=torch.float32, device=dl.device)
+    st = L.fn("umi_head_dgrad_bnred")(dl.data_ptr(), lddl, wp.data_ptr(), da.data_ptr(), ldda, ybn.data_ptr(), ldybn,
+                                      txbn.data_ptr(), rstd.data_ptr(), part.data_ptr(), P, Ci, Co, _dt(dl), _stream())
+    if st == -2:
+        return None
+    L.check(st, "umi_head_dgrad_bnred")
+    return part
+
+
 def bn_bwd(da, y, tx, rstd, partials=None, apply=True):
     """In place: da <- dy.  Returns (sum_dz, sum_dzx) = (d beta, d gamma) (still loss-scaled).  `partials`: stage-1 rows
     already produced by conv_dgrad_bnred for this layer (the reduction pass over `da` is skipped).  apply=False: the sums
