@@ -139,6 +139,16 @@ int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, void* da, in
                          const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co,
                          int dtype, umi_stream_t stream);
 
+/* The same fusion for the data gradients that run on the pointwise / tap-gather matrix-core kernel -- ConvTranspose2d(2,2)'s
+ * (a stride-2 2x2 conv over d(up), reference Model.py:56-57 under autograd), 1x1 convs', strided convs' (UMI_CONV_DGRAD_STRIDED):
+ * y = conv(x, wp8) as umi_conv_fwd computes it, plus part[rows][2][Co] of the BatchNorm(+ReLU) layer whose activated output y is
+ * the gradient of.  rows = umi_conv_gather_bnred_rows(...); 0 = the problem is not on that kernel (use the separate calls). */
+int umi_conv_gather_bnred_rows(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
+                               int ldx, int ldy, int dtype, int flags);
+int umi_conv_gather_bnred(const void* x, int ldx, const void* wp8, void* y, int ldy, const void* ybn, int ldybn,
+                          const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co, int R, int S,
+                          int stride, int pad, int Ho, int Wo, int dtype, int flags, umi_stream_t stream);
+
 /* The same fusion for the data gradient of the narrow pointwise head (`OutConv`, reference Model.py:89-93; Ci <= 8 logit channels):
  * da[p][c] = sum_k dl[p][k] * w[k][c] plus part[rows][2][Co], rows = umi_head_dgrad_bnred_rows(...) (0 = shape not taken, call
  * umi_conv_fwd and umi_bn_bwd_reduce).  wp: the generic [1][Ci][Co] fp16 packing (umi_pack_kn). */

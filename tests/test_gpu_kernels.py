@@ -531,6 +531,42 @@ def test_pool2_bwd_with_bn_reduction_matches_separate_kernels(shape, acc):
     torch.testing.assert_close(sums.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 6, 128, 64), (1, 16, 16, 64, 128), (2, 9, 37, 256, 128), (1, 40, 40, 128, 256)])
+def test_convT_dgrad_with_bn_reduction_matches_separate_kernels(shape):
+    """umi_conv_gather_bnred (ConvTranspose2d(2,2) data gradient on the tap-gather matrix-core kernel + stage 1 of the BatchNorm
+    backward of the layer below) against umi_conv_fwd followed by umi_bn_bwd_reduce: identical gradient tensor, sums equal up to
+    fp32 summation order.  The gradient arrives as a channel slice of a wider tensor, as in the U-Net's concat buffers."""
+    lib, ops = _gpu()
+    N, h, w, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    wt = (torch.randn(Cin, Cout, 2, 2, generator=g) * (1.0 / Cin) ** 0.5).to(DEV)
+    dupb = (torch.randn(N, 2 * h, 2 * w, 2 * Cout, generator=g) * 0.1).half().to(DEV)
+    dup = dupb[..., Cout:]
+    y = torch.randn(N, h, w, Cin, generator=g).half().to(DEV)          # raw output of the BatchNorm layer below the ConvT
+    t = _tx(Cin, g)
+    t[:, 0] = 0.1 * torch.randn(Cin, generator=g)
+    td = t.to(DEV).contiguous()
+    rstd = (0.5 + torch.rand(Cin, generator=g)).to(DEV)
+    wp = ops.pack_convT_dgrad(wt, torch.float16, k8=True)
+    dx_a = torch.empty(N, h, w, Cin, device=DEV, dtype=torch.float16)
+    dx_b = torch.empty_like(dx_a)
+    ops.conv_fwd(dup, None, lambda lay: wp, None, dx_a, 2, 2, 2, 0)
+    part = ops.conv_gather_bnred(dup, wp, dx_b, y, td, rstd, 2, 2, 2, 0)
+    assert part is not None
+    assert torch.equal(dx_a, dx_b)
+    sums = torch.empty(2, Cin, dtype=torch.float32, device=DEV)
+    lib.check(lib.fn("umi_bn_bwd_from_partials")(part.data_ptr(), part.numel() // (2 * Cin), Cin, sums[0].data_ptr(),
+                                                 sums[1].data_ptr(), ops._stream()), "from_partials")
+    ref = torch.empty(2, Cin, dtype=torch.float32, device=DEV)
+    M = N * h * w
+    nb = lib.fn("umi_bn_bwd_ws_bytes")(M, Cin)
+    ws = ops.workspace(nb, y.device)
+    lib.check(lib.fn("umi_bn_bwd_reduce")(dx_a.data_ptr(), Cin, y.data_ptr(), Cin, td.data_ptr(), rstd.data_ptr(), ref[0].data_ptr(),
+                                          ref[1].data_ptr(), M, Cin, lib.UMI_F16, ws.data_ptr(), ws.numel(), ops._stream()),
+              "reduce")
+    torch.testing.assert_close(sums.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 24, 64, 2), (1, 9, 7, 64, 4), (3, 32, 16, 128, 1), (1, 8, 8, 16, 8)])
 def test_head_dgrad_with_bn_reduction_matches_separate_kernels(shape):
     """umi_head_dgrad_bnred (OutConv's data gradient + stage 1 of the last DoubleConv's BatchNorm backward) against the narrow

@@ -23,7 +23,9 @@ int umi_conv3x3_mfma(const void* x, int ldx, const void* tx, const void* wp8, vo
 // conv1x1_mfma.hip
 bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int ldy, int in_dtype,
                          int out_dtype, int flags);
-struct UmiLinearEpi { int mode; float p; unsigned seed; const unsigned* seed_dev; void* mask; const void* aux; int ldaux; void* y2; int ldy2; };
+struct UmiLinearEpi { int mode; float p; unsigned seed; const unsigned* seed_dev; void* mask; const void* aux; int ldaux; void* y2; int ldy2;
+                      const void* bn_tx; const float* bn_rstd; float* bn_part; };
+int umi_conv1x1_bnred_rows(long M, int Ntot);
 int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y, int ldy,
                      int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int off_h,
                      int off_w, int out_H, int out_W, int flags, hipStream_t s, const UmiLinearEpi* epi = nullptr);
@@ -112,8 +114,31 @@ extern "C" int umi_linear_fused(const void* x, int ldx, const void* wp8, const f
     if ((epi == 1 && (!y2 || ldy2 % 8)) || (epi == 2 && (!aux || ldaux % 8))) return UMI_ERR_BADARG;
     if (dtype != UMI_F16 || !umi_conv1x1_mfma_ok(Ci, Co, 1, 1, 1, 0, ldx, ldy, UMI_F16, UMI_F16, 0)) return UMI_ERR_UNSUPPORTED;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wp8 | (uintptr_t)y2 | (uintptr_t)aux) & 15 || ((uintptr_t)mask & 7)) return UMI_ERR_UNSUPPORTED;
-    const UmiLinearEpi e{epi, p, seed, seed_dev, mask, aux, ldaux, y2, ldy2};
+    const UmiLinearEpi e{epi, p, seed, seed_dev, mask, aux, ldaux, y2, ldy2, nullptr, nullptr, nullptr};
     return umi_conv1x1_mfma(x, ldx, nullptr, wp8, bias, y, ldy, 1, 1, (int)M, Ci, Co, 1, 1, 1, 0, 1, (int)M, 0, 0, 1, (int)M, 0,
+                            (hipStream_t)stream, &e);
+}
+
+// A data gradient on the pointwise / tap-gather matrix-core kernel (ConvTranspose2d(2,2)'s = a stride-2 2x2 conv over d(up),
+// reference Model.py:56-57 under autograd; plain 1x1 convs; UMI_CONV_DGRAD_STRIDED) that also emits stage 1 of the BatchNorm(+ReLU)
+// backward of the layer whose activated output the gradient belongs to: part[rows][2][Co], rows = umi_conv_gather_bnred_rows(...)
+// (0 = not on that kernel: run umi_conv_fwd and umi_bn_bwd_reduce).  No transform, no bias, no accumulation.
+extern "C" int umi_conv_gather_bnred_rows(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo,
+                                          int ldx, int ldy, int dtype, int flags) {
+    if (flags & (UMI_CONV_UPSAMPLE2 | UMI_CONV_ACCUMULATE | UMI_CONV_FORCE_GENERIC)) return 0;
+    if (umi_conv3x3_mfma_ok(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, dtype, dtype, flags, nullptr)) return 0;
+    if (!umi_conv1x1_mfma_ok(Ci, Co, R, S, stride, pad, ldx, ldy, dtype, dtype, flags)) return 0;
+    return umi_conv1x1_bnred_rows((long)N * Ho * Wo, Co);
+}
+extern "C" int umi_conv_gather_bnred(const void* x, int ldx, const void* wp8, void* y, int ldy, const void* ybn, int ldybn,
+                                     const void* txbn, const float* rstd, float* part, int N, int H, int W, int Ci, int Co, int R,
+                                     int S, int stride, int pad, int Ho, int Wo, int dtype, int flags, umi_stream_t stream) {
+    if (!x || !wp8 || !y || !ybn || !txbn || !rstd || !part || N <= 0 || H <= 0 || W <= 0) return UMI_ERR_BADARG;
+    if (umi_conv_gather_bnred_rows(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, dtype, flags) <= 0 || ldybn % 8 || ldybn < Co)
+        return UMI_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wp8 | (uintptr_t)ybn) & 15) return UMI_ERR_BADARG;
+    const UmiLinearEpi e{3, 0.f, 0u, nullptr, nullptr, ybn, ldybn, nullptr, 0, txbn, rstd, part};
+    return umi_conv1x1_mfma(x, ldx, nullptr, wp8, nullptr, y, ldy, N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, 0, 0, Ho, Wo, flags,
                             (hipStream_t)stream, &e);
 }
 

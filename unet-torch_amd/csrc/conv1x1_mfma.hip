@@ -26,7 +26,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // epilogue fusion request of umi_linear_fused (api.hip); mode 0 = none
-struct UmiLinearEpi { int mode; float p; unsigned seed; const unsigned* seed_dev; void* mask; const void* aux; int ldaux; void* y2; int ldy2; };
+struct UmiLinearEpi { int mode; float p; unsigned seed; const unsigned* seed_dev; void* mask; const void* aux; int ldaux; void* y2; int ldy2;
+                      const void* bn_tx; const float* bn_rstd; float* bn_part; };   // mode 3: aux = the BatchNorm layer's raw output
 
 namespace {
 
@@ -55,6 +56,10 @@ struct Geo {                  // geometry of the (optionally strided) source / d
     unsigned char* mask;
     const half_t* aux; int ldaux;
     half_t* y2; int ldy2;
+    //   epi 3 (data gradients: ConvTranspose2d's, strided convs'): also stage 1 of the BatchNorm(+ReLU) backward of the layer whose
+    //          activated output this gradient belongs to (aux = that layer's raw output, bn_tx / bn_rstd its transform rows and
+    //          1/std): bn_part[pixel tile][2][columns] <- sums of dz and dz * xhat over the tile, dz = stored value * [tx(y) > lo]
+    const float4* bn_tx; const float* bn_rstd; float* bn_part;
 };
 
 __device__ __forceinline__ float c1_gelu(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
@@ -344,6 +349,16 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
         const int j = tid % PPR, p0 = tid / PPR;
         const int cop = c0 + j * 8;
         const bool col_ok = cop < Ntot_;
+        float4 bt[8];
+        float brs[8], bs[8], bq[8];
+        if (geo.epi == 3) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                bt[jj] = col_ok ? geo.bn_tx[cop + jj] : make_float4(0.f, 1.f, 0.f, 0.f);
+                brs[jj] = col_ok ? geo.bn_rstd[cop + jj] : 0.f;
+                bs[jj] = bq[jj] = 0.f;
+            }
+        }
         int co = cop, tdy = 0, tdx = 0;
         if (OUT_UPS) {
             const int tap = cop / Nc;
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
                 const half8 o = *reinterpret_cast<const half8*>(dst);
                 v = __builtin_bit_cast(uint4, (half8)(o + __builtin_bit_cast(half8, v)));
             }
-            if (geo.epi) {                  // dense mode (the launcher guarantees it): row m0 + p, columns cop .. cop + 7
+            if (geo.epi == 1 || geo.epi == 2) {   // dense mode (the launcher guarantees it): row m0 + p, columns cop .. cop + 7
                 const long e0 = (m0 + p) * (long)Ntot_ + cop;
                 const unsigned seed = geo.seed + (geo.seed_dev ? geo.seed_dev[0] * 0x9E3779B9u : 0u);
                 const float scale = 1.f / (1.f - geo.drop_p);
@@ -397,6 +412,35 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
             if (v.x == 0x12345678u)
 #endif
             *reinterpret_cast<uint4*>(dst) = v;
+            if (geo.epi == 3) {             // (plain / tap-gather modes: destination pixel = GEMM pixel, any ld)
+                const long drow = dense ? (m0 + p) : ((long)pi.x * geo.Hd + yy) * geo.Wd + xx;
+                const half8 yv = *reinterpret_cast<const half8*>(geo.aux + drow * geo.ldaux + cop);
+                const half8 hv = __builtin_bit_cast(half8, v);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float yy_ = (float)yv[jj];
+                    const float dz = umi_tx_pre(yy_, bt[jj]) > bt[jj].w ? (float)hv[jj] : 0.f;
+                    bs[jj] += dz;
+                    bq[jj] = fmaf(dz, (yy_ - bt[jj].x) * brs[jj], bq[jj]);
+                }
+            }
+        }
+        if (geo.epi == 3) {
+            __syncthreads();                                // every thread is done with the output tile: reuse it for the slice sums
+            float* rs_ = reinterpret_cast<float*>(smem);    // [2][PSTEP][BN]
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                rs_[(0 * PSTEP + p0) * BN + j * 8 + jj] = bs[jj];
+                rs_[(1 * PSTEP + p0) * BN + j * 8 + jj] = bq[jj];
+            }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int which = tid / BN, cc = tid % BN;
+                float a = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < PSTEP; ++k) a += rs_[(which * PSTEP + k) * BN + cc];
+                if (c0 + cc < Ntot_) geo.bn_part[((m0 / P) * 2 + which) * Ntot_ + c0 + cc] = a;
+            }
         }
     }
 }
@@ -446,11 +490,38 @@ bool umi_conv1x1_mfma_ok(int Ci, int Co, int R, int S, int stride, int pad, int 
     return true;
 }
 
+// tile of a problem with M pixels and Ntot output columns: the largest that still gives every CU two workgroups; small GEMMs (ViT
+// linears: 4,704 tokens x 768) take 128-pixel tiles, and 64-channel ones if that is still not enough.
+// ~0.6 of the 512 resident workgroup slots.  (400 sent the ViT's Q/K/V linear -- 4,704 x 768 -> 2,304: 342 tiles of 256 x 128 --
+// to 256 x 64 tiles: 35.2 us against 29.0, tools/ab_gemm.py; the other linears' picks are the same with either value.)
+static void c1_pick_tile(long M, int Ntot, int* P, int* BN) {
+    const bool bn128 = Ntot % 128 == 0;
+    const long want = 300;
+    const long b_256_128 = ((M + 255) / 256) * (Ntot / 128), b_128_128 = ((M + 127) / 128) * (Ntot / 128);
+    const long b_256_64 = ((M + 255) / 256) * (Ntot / 64);
+    // UMI_C1_TILE=PxBN: tile override for timing experiments (tools/ab_gemm.py); read per call
+    if (const char* e = getenv("UMI_C1_TILE")) {
+        const int p_ = atoi(e), bn_ = strchr(e, 'x') ? atoi(strchr(e, 'x') + 1) : 0;
+        if ((p_ == 256 || p_ == 128) && ((bn_ == 128 && bn128) || bn_ == 64)) { *P = p_; *BN = bn_; return; }
+    }
+    if (bn128 && b_256_128 >= want) { *P = 256; *BN = 128; return; }
+    if (b_256_64 >= want) { *P = 256; *BN = 64; return; }
+    if (bn128 && b_128_128 >= want) { *P = 128; *BN = 128; return; }
+    *P = 128; *BN = 64;
+}
+// partial-row count of the epi-3 (BatchNorm-reduce) epilogue for a problem of M pixels: one row per pixel tile
+int umi_conv1x1_bnred_rows(long M, int Ntot) {
+    int P, BN;
+    c1_pick_tile(M, Ntot, &P, &BN);
+    return (int)((M + P - 1) / P);
+}
+
 int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, const float* bias, void* y, int ldy,
                      int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int Ho, int Wo, int off_h,
                      int off_w, int out_H, int out_W, int flags, hipStream_t s, const UmiLinearEpi* epi) {
     const int mode = umi_conv1x1_mode(R, S, stride, pad, flags);
-    if (epi && epi->mode && (mode != 0 || (flags & UMI_CONV_ACCUMULATE) || Co % 8)) return UMI_ERR_UNSUPPORTED;
+    if (epi && epi->mode && epi->mode != 3 && (mode != 0 || (flags & UMI_CONV_ACCUMULATE) || Co % 8)) return UMI_ERR_UNSUPPORTED;
+    if (epi && epi->mode == 3 && (mode == 1 || Co % 8)) return UMI_ERR_UNSUPPORTED;        // (not for the scattering ConvT forward)
     Geo geo;
     long M;
     int Kc = Ci, Nc = Co, Ntot = Co, ntaps = 1;
@@ -469,34 +540,21 @@ int umi_conv1x1_mfma(const void* x, int ldx, const void* tx, const void* wp8, co
     // the gather / scatter modes address a source image with 31-bit byte offsets relative to the tile's first image (two
     // images in reach): refuse what does not fit instead of wrapping (~1 GB per image, no shipped config)
     if (mode != 0 && 2L * H * W * ldx * 2 >= 0x7FFFFFF0L) return UMI_ERR_UNSUPPORTED;
-    // largest tile that still gives every CU two workgroups; small GEMMs (ViT linears: 4,704 tokens x 768) take
-    // 128-pixel tiles, and 64-channel ones if that is still not enough
-    const bool bn128 = Ntot % 128 == 0;
-    // ~0.6 of the 512 resident workgroup slots.  (400 sent the ViT's Q/K/V linear -- 4,704 x 768 -> 2,304: 342 tiles of 256 x 128 --
-    // to 256 x 64 tiles: 35.2 us against 29.0, tools/ab_gemm.py; the other linears' picks are the same with either value.)
-    const long want = 300;
-    const long b_256_128 = ((M + 255) / 256) * (Ntot / 128), b_128_128 = ((M + 127) / 128) * (Ntot / 128);
-    const long b_256_64 = ((M + 255) / 256) * (Ntot / 64);
     geo.accum = (flags & UMI_CONV_ACCUMULATE) ? 1 : 0;
     geo.epi = 0; geo.drop_p = 0.f; geo.seed = 0; geo.seed_dev = nullptr; geo.mask = nullptr; geo.aux = nullptr; geo.ldaux = 0;
-    geo.y2 = nullptr; geo.ldy2 = 0;
+    geo.y2 = nullptr; geo.ldy2 = 0; geo.bn_tx = nullptr; geo.bn_rstd = nullptr; geo.bn_part = nullptr;
     if (epi && epi->mode) {
         geo.epi = epi->mode; geo.drop_p = epi->p; geo.seed = epi->seed; geo.seed_dev = epi->seed_dev;
         geo.mask = (unsigned char*)epi->mask; geo.aux = (const half_t*)epi->aux; geo.ldaux = epi->ldaux;
         geo.y2 = (half_t*)epi->y2; geo.ldy2 = epi->ldy2;
+        geo.bn_tx = (const float4*)epi->bn_tx; geo.bn_rstd = epi->bn_rstd; geo.bn_part = epi->bn_part;
     }
 #define GO(P_, BN_) return launch<P_, BN_>(mode == 2, mode == 1, x, ldx, tx, wp8, bias, y, ldy, M, Kc, Nc, Ntot, ntaps, geo, s)
-    // UMI_C1_TILE=PxBN: tile override for timing experiments (tools/ab_gemm.py); read per call
-    if (const char* e = getenv("UMI_C1_TILE")) {
-        const int p_ = atoi(e), bn_ = strchr(e, 'x') ? atoi(strchr(e, 'x') + 1) : 0;
-        if (p_ == 256 && bn_ == 128 && bn128) GO(256, 128);
-        if (p_ == 256 && bn_ == 64) GO(256, 64);
-        if (p_ == 128 && bn_ == 128 && bn128) GO(128, 128);
-        if (p_ == 128 && bn_ == 64) GO(128, 64);
-    }
-    if (bn128 && b_256_128 >= want) GO(256, 128);
-    if (b_256_64 >= want) GO(256, 64);
-    if (bn128 && b_128_128 >= want) GO(128, 128);
+    int tp, tbn;
+    c1_pick_tile(M, Ntot, &tp, &tbn);
+    if (tp == 256 && tbn == 128) GO(256, 128);
+    if (tp == 256) GO(256, 64);
+    if (tbn == 128) GO(128, 128);
     GO(128, 64);
 #undef GO
 }

@@ -448,8 +448,18 @@ class Tape:
                         a.gives += 1
                         return
                     dx = self.alloc(N, h, w, Cin, device=dest.device)
-                    ops.conv_fwd(g, None, lambda lay: self._pack("convT_dgrad", weight, wf, bool(lay)), None, dx,
-                                 2, 2, 2, 0)
+                    part = None
+                    if (_fuse_bnred() and os.environ.get("UMI_NO_CONVT_BNRED") != "1" and a.grad is None and a.parts is None
+                            and a.bn_rstd is not None and a.tx is not None and self.dtype == torch.float16 and g.dtype == torch.float16):
+                        # the transposed conv is the only consumer of the DoubleConv below it: stage 1 of that layer's BatchNorm
+                        # backward rides on its data gradient
+                        part = ops.conv_gather_bnred(g, self._pack("convT_dgrad", weight, wf, True), dx, a.raw, a.tx, a.bn_rstd,
+                                                     2, 2, 2, 0)
+                    if part is not None:
+                        a.bn_part, a.bn_part_at = part, a.gives + 1
+                    else:
+                        ops.conv_fwd(g, None, lambda lay: self._pack("convT_dgrad", weight, wf, bool(lay)), None, dx,
+                                     2, 2, 2, 0)
                     self._give(a, dx)
             self.steps.append(bwd)
         return o

@@ -115,6 +115,9 @@ SIGNATURES = {
                                     c_int, c_int, c_void_p]),
     "umi_conv_dgrad_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_conv_gather_bnred_rows": (c_int, [c_int] * 15),
+    "umi_conv_gather_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+                              + [c_int] * 13 + [c_void_p]),
     "umi_head_dgrad_bnred_rows": (c_int, [c_long, c_int, c_int, c_int, c_int]),
     "umi_head_dgrad_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_long, c_int, c_int, c_int, c_void_p]),

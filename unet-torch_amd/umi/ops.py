@@ -566,6 +566,30 @@ def conv_dgrad_bnred(dy, wp8, da, ybn, txbn, rstd):
     return part
 
 
+def conv_gather_bnred(x, wp8, y, ybn, txbn, rstd, R, S, stride, pad, flags=0):
+    """y <- conv(x, wp8) on the pointwise / tap-gather matrix-core kernel (no transform, no bias) plus stage 1 of the BatchNorm
+    backward reduction of the layer whose raw output is `ybn` (umi_conv_gather_bnred).  Returns the partial-sum tensor, or None when
+    the problem is not on that kernel (nothing was launched)."""
+    N, H, W, Ci, ldx = _nhwc(x)
+    _, Ho, Wo, Co, ldy = _nhwc(y)
+    ldybn = _nhwc(ybn)[4]
+    if x.dtype != torch.float16 or y.dtype != torch.float16 or ybn.dtype != torch.float16:
+        return None
+    if (x.data_ptr() | y.data_ptr() | ybn.data_ptr()) & 15:
+        return None
+    rows = L.fn("umi_conv_gather_bnred_rows")(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo, ldx, ldy, _dt(x), flags)
+    if rows <= 0:
+        return None
+    part = torch.empty(rows * 2 * Co, dtype=torch.float32, device=x.device)
+    st = L.fn("umi_conv_gather_bnred")(x.data_ptr(), ldx, wp8.data_ptr(), y.data_ptr(), ldy, ybn.data_ptr(), ldybn,
+                                       txbn.data_ptr(), rstd.data_ptr(), part.data_ptr(), N, H, W, Ci, Co, R, S, stride, pad,
+                                       Ho, Wo, _dt(x), flags, _stream())
+    if st == -2:
+        return None
+    L.check(st, "umi_conv_gather_bnred")
+    return part
+
+
 def head_dgrad_bnred(dl, wp, da, ybn, txbn, rstd):
     """Data gradient of a narrow pointwise conv (OutConv: <= 8 logit channels) that also emits stage 1 of the BatchNorm backward
     reduction of the layer `da` belongs to (umi_head_dgrad_bnred).  Returns the partial-sum tensor, or None when the shape is not
