@@ -204,6 +204,13 @@ int umi_conv_wgrad_deferred(const void* x, int ldx, const void* txa, const void*
                             int R, int S, int stride, int pad, int Ho, int Wo, int dtype, int flags, void* ws, size_t ws_bytes,
                             umi_wgrad_pending* out, umi_stream_t stream);
 int umi_wgrad_reduce_group(int n, const void* items /* umi_wgrad_pending[n], host */, umi_stream_t stream);
+/* Weight AND bias gradient of ConvTranspose2d(2,2) (reference Model.py:56-57 under autograd) in one pass over d(up): the arguments of
+ * umi_conv_wgrad_deferred for that layer (x = d(up) [N,H,W,Ci], dy = the ConvT's input [N,Ho,Wo,Co] with its transform txb) plus
+ * dbias[Ci] <- out_scale * column sums of x.  `out` NULL: the split-K reduction runs at once.  UMI_ERR_UNSUPPORTED (nothing
+ * launched) where the 2x2 / stride-2 matrix-core kernel does not apply: umi_colsum + umi_conv_wgrad. */
+int umi_conv_wgrad_bias(const void* x, int ldx, const void* dy, int lddy, const void* txb, float* dW, long s_co, long s_ci,
+                        long s_t, float* dbias, float out_scale, int N, int H, int W, int Ci, int Co, int Ho, int Wo, int dtype,
+                        int flags, void* ws, size_t ws_bytes, umi_wgrad_pending* out, umi_stream_t stream);
 /* umi_conv_wgrad (R = S = 1, no transforms) for `n` layers of one shape in one launch: the per-layer weight gradients of a
  * ViT encoder (reference vit_seg_modeling.py:58-62,100-101, twelve Blocks), whose pixel dimension (tokens) is too short to
  * fill the chip one layer at a time without a deep split-K.  x / dy / dW: HOST arrays of n device pointers.  No workspace,

@@ -532,6 +532,33 @@ def test_pool2_bwd_with_bn_reduction_matches_separate_kernels(shape, acc):
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 6, 128, 64), (1, 16, 16, 64, 128), (2, 9, 37, 256, 128), (1, 40, 40, 128, 256)])
+def test_convT_wgrad_with_bias_gradient_matches_separate_kernels(shape):
+    """umi_conv_wgrad_bias (ConvTranspose2d(2,2) weight gradient that also sums the upsampled gradient's columns = the bias gradient)
+    against umi_conv_wgrad + umi_colsum: the same weight gradient bit for bit, bias gradient equal up to fp32 summation order."""
+    lib, ops = _gpu()
+    N, h, w, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 9)
+    xin = torch.randn(N, h, w, Cin, generator=g).half().to(DEV)
+    t = _tx(Cin, g).to(DEV)
+    dupb = (torch.randn(N, 2 * h, 2 * w, 2 * Cout, generator=g) * 0.1).half().to(DEV)
+    dup = dupb[..., Cout:]                                   # a channel slice, as in the concat buffers
+    gw_a = torch.empty(Cin, Cout, 2, 2, device=DEV)
+    gw_b = torch.empty_like(gw_a)
+    gb_a = torch.empty(Cout, device=DEV)
+    gb_b = torch.empty_like(gb_a)
+    ops.conv_wgrad(dup, None, xin, t, gw_a, Cout * 4, 4, 1, 0.5, 2, 2, 2, 0)
+    ops.colsum(dup, gb_a, 0.5)
+    assert ops.convT_wgrad_bias(dup, xin, t, gw_b, gb_b, 0.5)
+    assert torch.equal(gw_a, gw_b)
+    torch.testing.assert_close(gb_b.cpu(), gb_a.cpu(), rtol=1e-4, atol=1e-4 * float(gb_a.abs().max()))
+    defer = []
+    gw_c, gb_c = torch.empty_like(gw_a), torch.empty_like(gb_a)
+    assert ops.convT_wgrad_bias(dup, xin, t, gw_c, gb_c, 0.5, defer=defer)
+    ops.wgrad_reduce_flush(defer)
+    assert torch.equal(gw_a, gw_c) and torch.equal(gb_b, gb_c)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 6, 128, 64), (1, 16, 16, 64, 128), (2, 9, 37, 256, 128), (1, 40, 40, 128, 256)])
 def test_convT_dgrad_with_bn_reduction_matches_separate_kernels(shape):
     """umi_conv_gather_bnred (ConvTranspose2d(2,2) data gradient on the tap-gather matrix-core kernel + stage 1 of the BatchNorm
     backward of the layer below) against umi_conv_fwd followed by umi_bn_bwd_reduce: identical gradient tensor, sums equal up to

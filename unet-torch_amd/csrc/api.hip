@@ -385,6 +385,26 @@ extern "C" int umi_conv_wgrad_deferred(const void* x, int ldx, const void* txa, 
     return st;
 }
 
+// ConvTranspose2d(2,2) weight gradient (called like umi_conv_wgrad_deferred for it: x = d(up), dy = the ConvT's input) that also
+// produces the BIAS gradient d bias[c] = out_scale * sum over pixels of x[.][c] from the operand tiles it stages (reference
+// Model.py:56-57 under autograd; replaces umi_colsum's pass over x).  UMI_ERR_UNSUPPORTED (nothing launched) where the 2x2 / stride-2
+// matrix-core kernel does not take the problem: run umi_colsum + umi_conv_wgrad instead.  `out` may be NULL (reduce at once).
+void umi_wgradT_bias_set(float* bias_out);
+extern "C" int umi_conv_wgrad_bias(const void* x, int ldx, const void* dy, int lddy, const void* txb, float* dW, long s_co,
+                                   long s_ci, long s_t, float* dbias, float out_scale, int N, int H, int W, int Ci, int Co, int Ho,
+                                   int Wo, int dtype, int flags, void* ws, size_t ws_bytes, umi_wgrad_pending* out,
+                                   umi_stream_t stream) {
+    if (!dbias) return UMI_ERR_BADARG;
+    if (!umi_wgradT_mfma_ok(H, W, Ci, Co, 2, 2, 2, 0, Ho, Wo, ldx, lddy, dtype, flags, nullptr)) return UMI_ERR_UNSUPPORTED;
+    if (out) { out->part = nullptr; umi_wgrad_defer_set(out); }
+    umi_wgradT_bias_set(dbias);
+    const int st = umi_conv_wgrad(x, ldx, nullptr, dy, lddy, txb, dW, s_co, s_ci, s_t, out_scale, N, H, W, Ci, Co, 2, 2, 2, 0, Ho, Wo,
+                                  dtype, flags, ws, ws_bytes, stream);
+    umi_wgradT_bias_set(nullptr);
+    umi_wgrad_defer_set(nullptr);
+    return st;
+}
+
 // umi_conv_wgrad for `n` pointwise convs / nn.Linear layers of ONE shape (M rows, Ci -> Co, same row strides) in one launch:
 // dW[i][co*s_co + ci*s_ci] = out_scale * sum_p x[i][p][ci] * dy[i][p][co].  No workspace: each output tile is owned by one
 // workgroup (fixed summation order).  UMI_ERR_UNSUPPORTED where the pointwise matrix-core kernel does not apply.

@@ -654,11 +654,14 @@ __device__ __forceinline__ half8 tr_frag_s2(const unsigned char* p) {      // pi
 // YH = 64-channel halves of the low-res operand per workgroup (1: 64 x 64 channel tile, 2: 64 x 128).  With 128 of them every staged
 // hi-res pixel (the operand that dominates the staging: 256 pixels x 64 channels per tile) feeds twice as many MFMAs -- 12 staged
 // pieces per 32 MFMAs and thread instead of 10 per 16 (round 3; 8 accumulator tiles = 128 registers per wave).
+// cpart != nullptr: the workgroups of the first cy tile also sum the hi-res operand's columns over their pixels -- the bias gradient of
+// the transposed conv, d bias[cx] = sum over all hi-res pixels of X[.][cx] -- from the pieces they stage anyway: cpart[split][2][Cx]
+// (slot 0), finished by reduce_rows2 (a pass of its own over the 537 MB gradient at the bench shape otherwise: umi_colsum).
 template <bool HAS_TX, int YH>
 __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
     const half_t* __restrict__ x, int ldx, const half_t* __restrict__ y, int ldy, const float4* __restrict__ txy,
     float* __restrict__ part, int N, int h, int w, int Cx, int Cy, int tiles_x, int tiles_y, int tiles_total,
-    int tiles_per_split, int n_cy_t) {
+    int tiles_per_split, int n_cy_t, float* __restrict__ cpart) {
     constexpr int SMEM_T = 2 * X2_CHUNK + 2 * YH * Y2_CHUNK;
     constexpr int KPY = KPY2 * YH;                           // piece k: pixel half k & 1... see y_lds
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_T];
@@ -690,6 +693,10 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     half8 xraw[KPX2], yraw[KPY];
     bool yvalid[KPY];
+    const bool csum = cpart != nullptr && (int)blockIdx.x % n_cy_t == 0;      // (workgroup-uniform)
+    float cs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
     half8 zero8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
@@ -739,6 +746,12 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
         }
 #pragma unroll
         for (int k = 0; k < KPX2; ++k) *reinterpret_cast<half8*>(smem + x_lds + k * 32 * PROW) = xraw[k];
+        if (csum) {                                      // (pieces outside the image were loaded as zeros)
+#pragma unroll
+            for (int k = 0; k < KPX2; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cs[j] += (float)xraw[k][j];
+        }
 #pragma unroll
         for (int k = 0; k < KPY; ++k)
             *reinterpret_cast<half8*>(smem + y_lds + (k % KPY2) * 32 * PROW + (k / KPY2) * 2 * Y2_CHUNK) = yraw[k];
@@ -761,6 +774,18 @@ __global__ __launch_bounds__(256, 2) void wgradT2x2_mfma_kernel(
         __syncthreads();
     }
 #undef UMI_ISSUE2
+    if (csum) {                                          // 32 pixel lanes per 8-channel group `sub` -> one value per channel
+        float* red = reinterpret_cast<float*>(smem);     // [32][64] (the tile loop ended with a barrier)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(tid >> 3) * 64 + sub * 8 + j] = cs[j];
+        __syncthreads();
+        if (tid < 64) {
+            float a = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) a += red[k * 64 + tid];
+            cpart[((long)blockIdx.y * 2 + 0) * Cx + cx0 + tid] = a;
+        }
+    }
 #pragma unroll
     for (int hh = 0; hh < YH; ++hh) {
         const int cy = cy0 + hh * 64 + wcy * 32 + (lane & 31);
@@ -1101,25 +1126,38 @@ bool umi_wgradT_mfma_ok(int H, int W, int Ci, int Co, int R, int S, int stride, 
 size_t umi_wgradT_mfma_ws_bytes(int N, int Ho, int Wo, int Ci, int Co) {
     int tx_, ty_, tt, splits, tps;
     planT(N, Ho, Wo, Ci, Co, &tx_, &ty_, &tt, &splits, &tps);
-    return (size_t)splits * 4 * Ci * Co * sizeof(float);
+    return (size_t)splits * 4 * Ci * Co * sizeof(float) + (size_t)splits * 2 * Ci * sizeof(float);    // slabs + bias-gradient rows
 }
+
+// one-shot request (set by umi_conv_wgrad_bias, consumed by the next umi_wgradT_mfma on this thread): also produce the hi-res
+// operand's column sums, scaled like dW
+static thread_local float* g_wgT_bias = nullptr;
+void umi_wgradT_bias_set(float* bias_out) { g_wgT_bias = bias_out; }
+void umi_launch_reduce_rows2(const float* ws, int rows, int C, float* out0, float* out1, float scale, hipStream_t s);
 
 int umi_wgradT_mfma(const void* x, int ldx, const void* dy, int lddy, const void* txb, float* dW, long s_co, long s_ci,
                     long s_t, float out_scale, int N, int Ho, int Wo, int Ci, int Co, void* ws, size_t ws_bytes,
                     hipStream_t s) {
     int tiles_x, tiles_y, tiles_total, splits, tps;
     planT(N, Ho, Wo, Ci, Co, &tiles_x, &tiles_y, &tiles_total, &splits, &tps);
-    if (ws_bytes < (size_t)splits * 4 * Ci * Co * sizeof(float)) return UMI_ERR_WORKSPACE;
+    float* const bias_out = g_wgT_bias;
+    g_wgT_bias = nullptr;
+    if (ws_bytes < (size_t)splits * 4 * Ci * Co * sizeof(float) + (bias_out ? (size_t)splits * 2 * Ci * sizeof(float) : 0)) return UMI_ERR_WORKSPACE;
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return UMI_ERR_BADARG;
+    float* const cpart = bias_out ? (float*)ws + (size_t)splits * 4 * Ci * Co : nullptr;
     const bool wide = Co % 128 == 0;
     const int n_cy_t = wide ? Co / 128 : Co / 64;
     dim3 grid((Ci / 64) * n_cy_t, splits), block(256);
 #define UMI_GO_T(HT, YH_)                                                                                        \
     hipLaunchKernelGGL((wgradT2x2_mfma_kernel<HT, YH_>), grid, block, 0, s, (const half_t*)x, ldx, (const half_t*)dy, lddy, \
-                       (const float4*)txb, (float*)ws, N, Ho, Wo, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_cy_t)
+                       (const float4*)txb, (float*)ws, N, Ho, Wo, Ci, Co, tiles_x, tiles_y, tiles_total, tps, n_cy_t, cpart)
     if (txb) { if (wide) UMI_GO_T(true, 2); else UMI_GO_T(true, 1); }
     else { if (wide) UMI_GO_T(false, 2); else UMI_GO_T(false, 1); }
 #undef UMI_GO_T
+    if (bias_out) {
+        UMI_LAUNCH_CHECK();
+        umi_launch_reduce_rows2(cpart, splits, Ci, bias_out, nullptr, out_scale, s);
+    }
     UMI_LAUNCH_CHECK();
     umi_launch_wgrad_reduce((const float*)ws, splits, 4, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
     UMI_LAUNCH_CHECK();

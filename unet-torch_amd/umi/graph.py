@@ -429,16 +429,22 @@ class Tape:
                 g = o.grad
                 if dY or dX:
                     g = g[:, oy:oy + 2 * h, ox:ox + 2 * w, :].contiguous()
+                gw = self._new_pgrad(weight)
+                dlist = self._defer_list(weight, gw)
+                fused = False
                 if bias is not None:
                     gb = self._new_pgrad(bias)
                     if bias_cancelled and self.training and not (dY or dX):
                         gb.zero_()
+                    elif os.environ.get("UMI_NO_CONVT_BIAS_FUSION") != "1" and ops.convT_wgrad_bias(g, a.raw, a.tx, gw, gb, inv,
+                                                                                                    defer=dlist):
+                        fused = True                     # the bias gradient rode on the weight gradient's pass over g
                     else:
                         ops.colsum(g, gb, inv)
                     self._set_pgrad(bias, gb)
-                gw = self._new_pgrad(weight)
                 # dW[ci][co][t] = sum_p act(a)[p][ci] * g[2p+t][co]: a wgrad with the roles of x and dy swapped
-                ops.conv_wgrad(g, None, a.raw, a.tx, gw, Cout * 4, 4, 1, inv, 2, 2, 2, 0, defer=self._defer_list(weight, gw))
+                if not fused:
+                    ops.conv_wgrad(g, None, a.raw, a.tx, gw, Cout * 4, 4, 1, inv, 2, 2, 2, 0, defer=dlist)
                 self._set_pgrad(weight, gw)
                 if _wants_grad(a):
                     tgt = self._accumulate_target(a, g, 2, 2, 2, 0)

@@ -115,6 +115,8 @@ SIGNATURES = {
                                     c_int, c_int, c_void_p]),
     "umi_conv_dgrad_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "umi_conv_wgrad_bias": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_long, c_long, c_long, c_void_p, c_float]
+                            + [c_int] * 9 + [c_void_p, c_size_t, c_void_p, c_void_p]),
     "umi_conv_gather_bnred_rows": (c_int, [c_int] * 15),
     "umi_conv_gather_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
                               + [c_int] * 13 + [c_void_p]),

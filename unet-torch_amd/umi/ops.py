@@ -691,6 +691,31 @@ def conv_wgrad(x, txa, dy, txb, dW, s_co, s_ci, s_t, out_scale, R, S, stride, pa
         defer.append((pend, ws, dW))
 
 
+def convT_wgrad_bias(g, y, txy, dW, dbias, out_scale, defer=None):
+    """Weight and bias gradient of ConvTranspose2d(2,2) in one pass over the upsampled map's gradient `g` (umi_conv_wgrad_bias);
+    `y`/`txy` = the transposed conv's input and its transform.  False where the matrix-core kernel does not take the problem
+    (nothing was launched: run colsum + conv_wgrad).  defer: as in conv_wgrad."""
+    import ctypes
+    N, H, W, Ci, ldx = _nhwc(g)
+    _, Ho, Wo, Co, lddy = _nhwc(y)
+    if g.dtype != torch.float16 or (H, W) != (2 * Ho, 2 * Wo):
+        return False
+    assert dW.dtype == torch.float32 and dW.is_contiguous() and dbias.dtype == torch.float32 and dbias.numel() == Ci
+    nb = L.fn("umi_conv_wgrad_ws_bytes")(N, Ho, Wo, Ci, Co, 2, 2, _dt(g), 0)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=g.device) if defer is not None else workspace(nb, g.device)
+    pend = _WgPending()
+    assert dW.numel() == Ci * Co * 4                 # [Co][Ci][2][2] = ConvTranspose2d's [in][out][2][2]: in = y's channels, out = g's
+    st = L.fn("umi_conv_wgrad_bias")(g.data_ptr(), ldx, y.data_ptr(), lddy, _ptr(txy), dW.data_ptr(), Ci * 4, 4, 1, dbias.data_ptr(),
+                                     out_scale, N, H, W, Ci, Co, Ho, Wo, _dt(g), 0, ws.data_ptr(), ws.numel(),
+                                     ctypes.addressof(pend) if defer is not None else None, _stream())
+    if st == -2:
+        return False
+    L.check(st, "umi_conv_wgrad_bias")
+    if defer is not None and pend.part:
+        defer.append((pend, ws, dW))
+    return True
+
+
 def wgrad_reduce_flush(defer):
     """Run the reductions recorded by conv_wgrad(defer=...) and empty the list."""
     import ctypes
