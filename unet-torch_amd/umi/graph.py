@@ -193,7 +193,11 @@ class Tape:
                                "no CPU fallback exists in the product path")
         N, C, H, W = x.shape
         raw = torch.empty((N, H, W, C), dtype=self.dtype, device=x.device)
-        raw.copy_(x.permute(0, 2, 3, 1))               # NCHW -> NHWC + dtype cast in one pass
+        if C == 1 and x.is_contiguous():
+            raw.view(-1).copy_(x.view(-1))             # one channel: NCHW and NHWC are the same bytes -- a flat cast (the strided
+                                                       # copy below takes 81 us for the bench's 16 x 1 x 512 x 512 batch, this 10)
+        else:
+            raw.copy_(x.permute(0, 2, 3, 1))           # NCHW -> NHWC + dtype cast in one pass
         a = Act(raw, None, needs_grad=needs_grad)
         self._inputs.append(a)
         return a
