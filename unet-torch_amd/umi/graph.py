@@ -77,6 +77,7 @@ class Tape:
         self.steps = []
         self.param_grads = {}             # id(param) -> (param, grad tensor)
         self._deferred_unscale = []       # BatchNorm parameter gradients still carrying the loss scale
+        self._deferred_zero = []          # gradients that are identically zero (conv bias under a BatchNorm): one fill at the end
         self._nbt = []
         self._wgrad_deferred = None
         # Deferred fills: a gradient buffer registered in param_grads whose CONTENT is only written (with `=`) by a grouped
@@ -305,7 +306,14 @@ class Tape:
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
-                    gb.zero_()                       # d/d bias of BatchNorm(conv + bias) vanishes identically
+                    # d/d bias of BatchNorm(conv + bias) vanishes identically: zero-filled with the other such gradients by ONE
+                    # multi-tensor launch at the end of the backward pass (18 fills per U-Net step otherwise); with a gradient
+                    # sink the slot must be final before it is handed over
+                    if self.grad_sink is None:
+                        self._deferred_zero.append(gb)
+                        self._mark_deferred_fill(gb)     # a second use of the bias in this tape parks its addition behind the fill
+                    else:
+                        gb.zero_()
                     self._set_pgrad(bias, gb)
                 if _wants_grad(a):
                     if stride != 1:
@@ -587,6 +595,9 @@ class Tape:
         to the gradient sink."""
         if self._wgrad_deferred:
             ops.wgrad_reduce_flush(self._wgrad_deferred)     # the split-K reductions of all layers, 16 per launch
+        if self._deferred_zero:
+            torch._foreach_zero_(self._deferred_zero)        # (a deferred fill like the others: before the parked additions)
+            self._deferred_zero = []
         self._finish_param_grads()
         for dst, src in self._late_adds:                    # second uses of a parameter whose first gradient was a deferred fill
             dst.add_(src)
