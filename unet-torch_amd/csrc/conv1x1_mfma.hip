@@ -366,8 +366,24 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
             tdy = (tap >> 1) + geo.doy;
             tdx = (tap & 1) + geo.dox;
         }
-#pragma unroll 4
-        for (int p = p0; p < P; p += PSTEP) {
+        // epi 3: the BatchNorm layer's raw outputs of this thread's pixels, all loads up front (one dependent load per trip of the
+        // store loop otherwise: the ConvT data gradients went 0.54 -> 0.77 ms per step with it, i.e. nothing was gained)
+        constexpr int NPS = P / PSTEP;
+        half8 ybv[NPS];
+        if (geo.epi == 3 && !OUT_UPS) {
+#pragma unroll
+            for (int k = 0; k < NPS; ++k) {
+                const int p = p0 + k * PSTEP;
+                if (m0 + p < M && col_ok) {
+                    const int2 pi = dense ? make_int2(0, 0) : pixinfo[p];
+                    const long drow = dense ? (m0 + p) : ((long)pi.x * geo.Hd + (pi.y >> 16)) * geo.Wd + (pi.y & 0xffff);
+                    ybv[k] = *reinterpret_cast<const half8*>(geo.aux + drow * geo.ldaux + cop);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPS; ++k) {
+            const int p = p0 + k * PSTEP;
             if (m0 + p >= M || !col_ok) break;
             const int2 pi = dense ? make_int2(0, 0) : pixinfo[p];
             int yy = pi.y >> 16, xx = pi.y & 0xffff;
@@ -412,9 +428,8 @@ __global__ __launch_bounds__(256, (P == 128 && BN == 64) ? UMI_C1_OCC128 : 2) vo
             if (v.x == 0x12345678u)
 #endif
             *reinterpret_cast<uint4*>(dst) = v;
-            if (geo.epi == 3) {             // (plain / tap-gather modes: destination pixel = GEMM pixel, any ld)
-                const long drow = dense ? (m0 + p) : ((long)pi.x * geo.Hd + yy) * geo.Wd + xx;
-                const half8 yv = *reinterpret_cast<const half8*>(geo.aux + drow * geo.ldaux + cop);
+            if (geo.epi == 3 && !OUT_UPS) {  // (plain / tap-gather modes: destination pixel = GEMM pixel, any ld)
+                const half8 yv = ybv[k];
                 const half8 hv = __builtin_bit_cast(half8, v);
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
