@@ -220,7 +220,8 @@ int umi_conv_wgrad_group(int n, const void* const* x, int ldx, const void* const
 /* umi_conv_wgrad of a 3x3/stride-1/pad-1 conv fused with umi_bn_bwd_apply of the BatchNorm(+ReLU) that follows the conv
  * (reference Model.py:14-21 DoubleConv backward: autograd runs cudnn_batch_norm_backward, then convolution_backward):
  * `da` = gradient of the activated output (read only), `y`/`tx_bn`/`rstd`/`sum_dz`/`sum_dzx` as umi_bn_bwd_apply takes them;
- * `dz` (a separate tensor) receives exactly what umi_bn_bwd_apply would have left in `da`, dW what umi_conv_wgrad would
+ * `dz` (a separate tensor) receives exactly what umi_bn_bwd_apply would have left in `da` (dz == NULL: the layer's input takes no
+ * gradient, nothing else reads dz -- accepted for the network's first conv, Ci <= 4, whose kernel then never stores it), dW what umi_conv_wgrad would
  * have produced from it.  UMI_ERR_UNSUPPORTED where the fused kernel does not apply (run the two calls instead). */
 int umi_conv_wgrad_bnapply(const void* x, int ldx, const void* txa, const void* da, int ldda, const void* y, int ldy,
                            const void* tx_bn, const float* rstd, const float* sum_dz, const float* sum_dzx, void* dz,

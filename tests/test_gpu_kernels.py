@@ -628,6 +628,31 @@ def test_head_dgrad_with_bn_reduction_matches_separate_kernels(shape):
     torch.testing.assert_close(sums.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 29, 1, 64), (1, 16, 48, 3, 64), (3, 9, 70, 1, 32)])
+def test_stem_wgrad_with_bn_backward_apply_matches_separate_kernels(shape):
+    """umi_conv_wgrad_bnapply with dz = NULL on the network's first conv (<= 4 input channels, input takes no gradient): the
+    narrow-input weight-gradient kernel forms stage 3 of the BatchNorm backward on the fly; same weight gradient as
+    umi_bn_bwd_apply followed by umi_conv_wgrad, bit for bit (same expression, same rounding, same summation order)."""
+    lib, ops = _gpu()
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(sum(shape) + 3)
+    x = torch.randn(N, H, W, Ci, generator=g).half().to(DEV)
+    y = torch.randn(N, H, W, Co, generator=g).half().to(DEV)
+    t = _tx(Co, g)
+    t[:, 0] = 0.1 * torch.randn(Co, generator=g)
+    td = t.to(DEV).contiguous()
+    rstd = (0.5 + torch.rand(Co, generator=g)).to(DEV)
+    da = (torch.randn(N, H, W, Co, generator=g) * 0.1).half().to(DEV)
+    sums = (torch.randn(2, Co, generator=g) * 0.05 * N * H * W).to(DEV)
+    gw_a = torch.empty(Co, Ci, 3, 3, device=DEV)
+    gw_b = torch.empty_like(gw_a)
+    assert ops.conv_wgrad_bnapply(x, None, da, y, td, rstd, sums[0], sums[1], None, gw_b, Ci * 9, 9, 1, 0.25, 3, 3, 1, 1)
+    dz = da.clone()
+    ops.bn_bwd_apply(dz, y, td, rstd, sums[0], sums[1])
+    ops.conv_wgrad(x, None, dz, None, gw_a, Ci * 9, 9, 1, 0.25, 3, 3, 1, 1)
+    assert torch.equal(gw_a, gw_b)
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 64, 64, 64), (1, 13, 37, 72, 136), (3, 8, 32, 128, 64), (1, 5, 70, 16, 24),
                                    (2, 64, 64, 64, 128)])
 @pytest.mark.parametrize("strided", [False, True])

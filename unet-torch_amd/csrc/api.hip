@@ -37,6 +37,10 @@ int umi_stem_fwd(const void* x, int ldx, const void* tx, const void* wp, void* y
                  int Ci, int Co, hipStream_t s);
 bool umi_stem_wgrad_ok(int Ci, int Co, int R, int S, int stride, int pad, int lddy, int dtype, int flags, const void* txb);
 size_t umi_stem_wgrad_ws_bytes(int N, int H, int W, int Ci, int Co);
+int umi_stem_wgrad_bnapply(const void* x, int ldx, const void* txa, const void* da, int ldda, const void* y, int ldy,
+                           const void* tx_bn, const float* rstd, const float* sum_dz, const float* sum_dzx, float* dW, long s_co,
+                           long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws, size_t ws_bytes,
+                           hipStream_t s);
 int umi_stem_wgrad(const void* x, int ldx, const void* txa, const void* dy, int lddy, float* dW, long s_co, long s_ci,
                    long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws, size_t ws_bytes, hipStream_t s);
 bool umi_head_fwd_ok(int Ci, int Co, int R, int S, int stride, int pad, int ldx, int in_dtype, int out_dtype, int flags);
@@ -428,6 +432,16 @@ extern "C" int umi_conv_wgrad_bnapply(const void* x, int ldx, const void* txa, c
                                       void* dz, int lddz, float* dW, long s_co, long s_ci, long s_t, float out_scale, int N,
                                       int H, int W, int Ci, int Co, int R, int S, int stride, int pad, int dtype, int flags,
                                       void* ws, size_t ws_bytes, umi_stream_t stream) {
+    if (!dz) {
+        // dz == NULL: nothing else needs dz (the layer's input takes no gradient: the network's first conv) -- the narrow-input
+        // weight-gradient kernel forms it on the fly and never stores it
+        if (!x || !da || !y || !tx_bn || !rstd || !sum_dz || !sum_dzx || !dW || !ws || N <= 0 || H <= 0 || W <= 0 || Ci <= 0 ||
+            Co <= 0 || ldx < Ci || ldda < Co || ldy < Co)
+            return UMI_ERR_BADARG;
+        if (!umi_stem_wgrad_ok(Ci, Co, R, S, stride, pad, ldda, dtype, flags, nullptr) || ldy % 8) return UMI_ERR_UNSUPPORTED;
+        return umi_stem_wgrad_bnapply(x, ldx, txa, da, ldda, y, ldy, tx_bn, rstd, sum_dz, sum_dzx, dW, s_co, s_ci, s_t, out_scale,
+                                      N, H, W, Ci, Co, ws, ws_bytes, (hipStream_t)stream);
+    }
     if (!x || !da || !y || !tx_bn || !rstd || !sum_dz || !sum_dzx || !dz || !dW || !ws || N <= 0 || H <= 0 || W <= 0 ||
         Ci <= 0 || Co <= 0 || ldx < Ci || ldda < Co || ldy < Co || lddz < Co || dz == da || dz == y)
         return UMI_ERR_BADARG;

@@ -127,12 +127,19 @@ __global__ __launch_bounds__(256) void stem3x3_fwd_kernel(const half_t* __restri
     }
 }
 
+// BNA: `dy` is the gradient of the ACTIVATED output and the BatchNorm(+ReLU) backward's stage 3 -- dz = gamma*rstd*(relu'(z)*dA - c1 -
+// xhat*c2), umi_bn_dz (common.h), rounded to fp16 exactly as bn_bwd_apply_v8 stores it -- is formed on the fly from (dA, y).  The stem's
+// input needs no gradient, so nothing else reads dz: the apply pass over the layer's 537 MB tensors (read dA, read y, write dz) and
+// this kernel's read of dz become one read of dA and y.
+struct StemBna { const half_t* y; int ldy; const float4* tx; const float* rstd; const float* sum_dz; const float* sum_dzx; long M; };
+
 // dW[co][ci][tap] partials: grid = (pixel blocks, Ci); thread = (pixel lane, 8 output channels)
+template <bool BNA>
 __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const half_t* __restrict__ x, int ldx,
                                                             const float4* __restrict__ tx,
                                                             const half_t* __restrict__ dy, int lddy,
                                                             float* __restrict__ part, int N, int H, int W, int Ci,
-                                                            int Co) {
+                                                            int Co, StemBna ba) {
     __shared__ float red[256][9];
     const int tid = threadIdx.x, ci = blockIdx.y;
     const int G = Co >> 3, PL = 256 / G;
@@ -145,6 +152,19 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const half_t* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
     float4 tc = tx ? tx[ci] : make_float4(0.f, 1.f, 0.f, -INFINITY);
+    float4 tb[BNA ? 8 : 1];
+    float rsb[BNA ? 8 : 1], c1[BNA ? 8 : 1], c2[BNA ? 8 : 1];
+    if (BNA) {
+        const float invM = 1.f / (float)ba.M;            // on the device, as the standalone kernels compute it
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            tb[j] = ba.tx[c];
+            rsb[j] = ba.rstd[c];
+            c1[j] = ba.sum_dz[c] * invM;
+            c2[j] = ba.sum_dzx[c] * invM;
+        }
+    }
     // Pixels are dealt to the PL pixel lanes round-robin: per trip a workgroup reads PL ADJACENT pixels of dy (PL x 128 B contiguous
     // at Co = 64).  (Round 1 gave every lane its own contiguous run -- a sliding 3x3 window, three input loads per pixel instead
     // of nine -- which made 32 K concurrent 128-byte streams of the 537 MB gradient tensor: 1.5 TB/s.  The nine input values
@@ -178,8 +198,14 @@ __global__ __launch_bounds__(256) void stem3x3_wgrad_kernel(const half_t* __rest
             }
         }
         float gf[8];
+        if (BNA) {
+            const half8 yv = *reinterpret_cast<const half8*>(ba.y + p * ba.ldy + cg * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gf[j] = (float)g[j];
+            for (int j = 0; j < 8; ++j) gf[j] = (float)umi_bn_dz<_Float16>((float)yv[j], (float)g[j], tb[j], rsb[j], c1[j], c2[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gf[j] = (float)g[j];
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -457,8 +483,24 @@ int umi_stem_wgrad(const void* x, int ldx, const void* txa, const void* dy, int 
     if (ws_bytes < umi_stem_wgrad_ws_bytes(N, H, W, Ci, Co)) return UMI_ERR_WORKSPACE;
     if (!al16(dy)) return UMI_ERR_BADARG;
     int blocks = (int)(((long)N * H * W + WG_PPB - 1) / WG_PPB);
-    hipLaunchKernelGGL(stem3x3_wgrad_kernel, dim3(blocks, Ci), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txa,
-                       (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co);
+    hipLaunchKernelGGL(stem3x3_wgrad_kernel<false>, dim3(blocks, Ci), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txa,
+                       (const half_t*)dy, lddy, (float*)ws, N, H, W, Ci, Co, StemBna{});
+    UMI_LAUNCH_CHECK();
+    umi_launch_wgrad_reduce((const float*)ws, blocks, 9, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
+    UMI_LAUNCH_CHECK();
+    return UMI_OK;
+}
+// the same with stage 3 of the following BatchNorm's backward formed on the fly (da = gradient of the activated output)
+int umi_stem_wgrad_bnapply(const void* x, int ldx, const void* txa, const void* da, int ldda, const void* y, int ldy,
+                           const void* tx_bn, const float* rstd, const float* sum_dz, const float* sum_dzx, float* dW, long s_co,
+                           long s_ci, long s_t, float out_scale, int N, int H, int W, int Ci, int Co, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
+    if (ws_bytes < umi_stem_wgrad_ws_bytes(N, H, W, Ci, Co)) return UMI_ERR_WORKSPACE;
+    if (!al16(da) || !al16(y)) return UMI_ERR_BADARG;
+    int blocks = (int)(((long)N * H * W + WG_PPB - 1) / WG_PPB);
+    const StemBna ba{(const half_t*)y, ldy, (const float4*)tx_bn, rstd, sum_dz, sum_dzx, (long)N * H * W};
+    hipLaunchKernelGGL(stem3x3_wgrad_kernel<true>, dim3(blocks, Ci), dim3(256), 0, s, (const half_t*)x, ldx, (const float4*)txa,
+                       (const half_t*)da, ldda, (float*)ws, N, H, W, Ci, Co, ba);
     UMI_LAUNCH_CHECK();
     umi_launch_wgrad_reduce((const float*)ws, blocks, 9, Ci, Co, dW, s_co, s_ci, s_t, out_scale, s);
     UMI_LAUNCH_CHECK();

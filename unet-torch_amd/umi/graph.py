@@ -280,7 +280,11 @@ class Tape:
                 # pass that turns o.grad into d(raw conv output)) is done by that kernel's producer waves
                 fuse = (_fuse_bnapply(Ci) and self.dtype == torch.float16 and (R, S, stride, pad) == (3, 3, 1, 1)
                         and Ci % 8 == 0 and Co % 8 == 0)
-                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd, partials=partials, apply=not fuse)
+                # the network's first conv (<= 4 input channels that take no gradient): only its weight gradient reads dz, and the
+                # narrow-input kernel forms it on the fly (no apply pass, dz never stored)
+                stem_fuse = (not fuse and self.dtype == torch.float16 and (R, S, stride, pad) == (3, 3, 1, 1) and Ci <= 4
+                             and Co % 8 == 0 and not _wants_grad(a) and os.environ.get("UMI_NO_STEM_BNAPPLY") != "1")
+                dbeta, dgamma = ops.bn_bwd(o.grad, out, tx, rstd, partials=partials, apply=not (fuse or stem_fuse))
                 o.bn_part = None
                 if self.grad_sink is None and inv != 1.0:
                     # un-scale all BatchNorm parameter gradients with one batched multiply at the end of the backward
@@ -300,7 +304,12 @@ class Tape:
                     else:
                         fuse = False
                         ops.bn_bwd_apply(o.grad, out, tx, rstd, dbeta, dgamma)
-                if not fuse:
+                if stem_fuse:
+                    if not ops.conv_wgrad_bnapply(a.raw, a.tx, o.grad, out, tx, rstd, dbeta, dgamma, None, gw, Ci * R * S, R * S, 1,
+                                                  inv, R, S, stride, pad):
+                        stem_fuse = False
+                        ops.bn_bwd_apply(o.grad, out, tx, rstd, dbeta, dgamma)
+                if not fuse and not stem_fuse:
                     ops.conv_wgrad(a.raw, a.tx, o.grad, None, gw, Ci * R * S, R * S, 1, inv, R, S, stride, pad,
                                    defer=self._defer_list(weight, gw))
                 self._set_pgrad(weight, gw)

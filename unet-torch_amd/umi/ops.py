@@ -648,12 +648,13 @@ def conv_wgrad_bnapply(x, txa, da, y, tx_bn, rstd, sum_dz, sum_dzx, dz, dW, s_co
     _, Ho, Wo, Co, ldda = _nhwc(da)
     if (Ho, Wo) != (H, W) or da.dtype != torch.float16:
         return False
-    assert dW.dtype == torch.float32 and dW.is_contiguous() and dz.shape == da.shape
+    assert dW.dtype == torch.float32 and dW.is_contiguous() and (dz is None or dz.shape == da.shape)
     nb = L.fn("umi_conv_wgrad_ws_bytes")(N, Ho, Wo, Ci, Co, R, S, _dt(x), 0)
     ws = workspace(nb, x.device)
+    # dz None: the layer's input takes no gradient, nothing else reads dz (the network's first conv: formed on the fly, never stored)
     st = L.fn("umi_conv_wgrad_bnapply")(x.data_ptr(), ldx, _ptr(txa), da.data_ptr(), ldda, y.data_ptr(), _nhwc(y)[4],
                                         tx_bn.data_ptr(), rstd.data_ptr(), sum_dz.data_ptr(), sum_dzx.data_ptr(),
-                                        dz.data_ptr(), _nhwc(dz)[4], dW.data_ptr(), s_co, s_ci, s_t, out_scale,
+                                        _ptr(dz), _nhwc(dz)[4] if dz is not None else 0, dW.data_ptr(), s_co, s_ci, s_t, out_scale,
                                         N, H, W, Ci, Co, R, S, stride, pad, _dt(x), 0, ws.data_ptr(), ws.numel(), _stream())
     if st == -2:                                   # UMI_ERR_UNSUPPORTED: not an error, the caller runs the two passes
         return False
