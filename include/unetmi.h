@@ -156,6 +156,12 @@ int umi_head_dgrad_bnred_rows(long P, int Ci, int Co, int ldda, int dtype);
 int umi_head_dgrad_bnred(const void* dl, int lddl, const void* wp, void* da, int ldda, const void* ybn, int ldybn,
                          const void* txbn, const float* rstd, float* part, long P, int Ci, int Co, int dtype,
                          umi_stream_t stream);
+/* ... and the head's weight gradient from the same pass (its input is the activated ybn): dW[k * s_co + c * s_ci] <- out_scale *
+ * sum_p tx(ybn[p][c]) * dl[p][k] (k < Ci logit channels, c < Co feature channels).  ws: umi_head_bwd_fused_ws_bytes. */
+size_t umi_head_bwd_fused_ws_bytes(long P, int Ci, int Co);
+int umi_head_bwd_fused(const void* dl, int lddl, const void* wp, void* da, int ldda, const void* ybn, int ldybn,
+                       const void* txbn, const float* rstd, float* part, float* dW, long s_co, long s_ci, float out_scale,
+                       void* ws, size_t ws_bytes, long P, int Ci, int Co, int dtype, umi_stream_t stream);
 
 /* Inference form of Conv2d(3, pad 1, bias=False) -> BatchNorm2d (running statistics) -> ReLU (reference Model.py:15-22 under
  * model.eval(), the evaluation loop test_mc3serousv5.py:877-887): the layer's own transform out_tx[Co] = {mean, scale, shift,

@@ -626,6 +626,14 @@ def test_head_dgrad_with_bn_reduction_matches_separate_kernels(shape):
                                           ref[1].data_ptr(), M, C, lib.UMI_F16, ws.data_ptr(), ws.numel(), ops._stream()),
               "reduce")
     torch.testing.assert_close(sums.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    # ... and with the head's weight gradient from the same pass (umi_head_bwd_fused) against umi_conv_wgrad
+    gw_ref = torch.empty(ncls, C, 1, 1, device=DEV)
+    ops.conv_wgrad(y, td, dl, None, gw_ref, C, 1, 1, 0.5, 1, 1, 1, 0)
+    gw = torch.empty_like(gw_ref)
+    da_c = torch.empty_like(da_a)
+    part2 = ops.head_dgrad_bnred(dl, wp, da_c, y, td, rstd, dW=gw, out_scale=0.5)
+    assert part2 is not None and torch.equal(da_c, da_a) and torch.equal(part2, part)
+    torch.testing.assert_close(gw.cpu(), gw_ref.cpu(), rtol=2e-4, atol=2e-4 * float(gw_ref.abs().max()))
 
 
 @pytest.mark.parametrize("shape", [(2, 37, 29, 1, 64), (1, 16, 48, 3, 64), (3, 9, 70, 1, 32)])

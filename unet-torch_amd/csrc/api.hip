@@ -191,7 +191,8 @@ extern "C" int umi_conv_dgrad_bnred(const void* dy, int lddy, const void* wp8, v
 
 int umi_smallk_bnred_rows(long P, int Co);
 int umi_smallk_fwd_bnred(const void* x, int ldx, const void* wp, void* y, int ldy, const void* ybn, int ldybn, const void* txbn,
-                         const float* rstd, float* part, long P, int Ci, int Co, hipStream_t s);
+                         const float* rstd, float* part, long P, int Ci, int Co, hipStream_t s, float* dW = nullptr, long s_co = 0,
+                         long s_ci = 0, float out_scale = 1.f, void* ws = nullptr, size_t ws_bytes = 0);
 
 // The same fusion for the data gradient of a narrow pointwise conv (the segmentation head `OutConv`, reference Model.py:89-93:
 // Ci <= 8 logit channels -> Co feature channels): da = dl * W^T plus stage 1 of the BatchNorm+ReLU backward of the layer whose
@@ -207,6 +208,20 @@ extern "C" int umi_head_dgrad_bnred(const void* dl, int lddl, const void* wp, vo
     if (!umi_smallk_fwd_ok(Ci, Co, 1, 1, 1, 0, ldda, dtype, dtype, 0, nullptr, nullptr) || ldybn % 8 || ldybn < Co || lddl < Ci)
         return UMI_ERR_UNSUPPORTED;
     return umi_smallk_fwd_bnred(dl, lddl, wp, da, ldda, ybn, ldybn, txbn, rstd, part, P, Ci, Co, (hipStream_t)stream);
+}
+// ... and the head's WEIGHT gradient as well (reference Model.py:89-93 under autograd: dW[k][c] = sum_p act(ybn)[p][c] * dl[p][k]; the
+// head's input is the activated ybn): dW[k * s_co + c * s_ci] <- out_scale * that.  ws: umi_head_bwd_fused_ws_bytes(P, Ci, Co).
+extern "C" size_t umi_head_bwd_fused_ws_bytes(long P, int Ci, int Co) {
+    return (size_t)umi_smallk_bnred_rows(P, Co) * Co * Ci * sizeof(float);
+}
+extern "C" int umi_head_bwd_fused(const void* dl, int lddl, const void* wp, void* da, int ldda, const void* ybn, int ldybn,
+                                  const void* txbn, const float* rstd, float* part, float* dW, long s_co, long s_ci, float out_scale,
+                                  void* ws, size_t ws_bytes, long P, int Ci, int Co, int dtype, umi_stream_t stream) {
+    if (!dl || !wp || !da || !ybn || !txbn || !rstd || !part || !dW || !ws || P <= 0) return UMI_ERR_BADARG;
+    if (!umi_smallk_fwd_ok(Ci, Co, 1, 1, 1, 0, ldda, dtype, dtype, 0, nullptr, nullptr) || ldybn % 8 || ldybn < Co || lddl < Ci)
+        return UMI_ERR_UNSUPPORTED;
+    return umi_smallk_fwd_bnred(dl, lddl, wp, da, ldda, ybn, ldybn, txbn, rstd, part, P, Ci, Co, (hipStream_t)stream, dW, s_co, s_ci,
+                                out_scale, ws, ws_bytes);
 }
 
 int umi_conv3x3_mfma_act(const void* x, int ldx, const void* tx, const void* wp8, const void* out_tx, void* y, int ldy, int N,

@@ -341,18 +341,20 @@ __global__ __launch_bounds__(256) void smallk1x1_fwd_kernel(const half_t* __rest
 // The same data gradient + stage 1 of the BatchNorm(+ReLU) backward of the layer whose activated output `da` is the gradient of
 // (ybn / txbn / rstd = that layer's raw output, transform rows and 1/std): part[block][2][C] <- sums of dz and dz * xhat over the
 // block's pixels, dz = stored (rounded) da * [tx(y) > lo] -- what bn_bwd_reduce1_v8 computes in a pass of its own over da and y.
+// wpart != nullptr: also the head's WEIGHT gradient partials wpart[block][C][NC] = sum_p tx(ybn[p][c]) * x[p][k] -- the head's input is the
+// activated ybn, which this kernel reads anyway (head1x1_wgrad_kernel's pass over the 537 MB tensor goes away).
 template <int NC>
 __global__ __launch_bounds__(256) void smallk1x1_bnred_kernel(const half_t* __restrict__ x, int ldx,
                                                               const half_t* __restrict__ wp, half_t* __restrict__ y,
                                                               int ldy, const half_t* __restrict__ ybn, int ldybn,
                                                               const float4* __restrict__ txbn, const float* __restrict__ rstd,
-                                                              float* __restrict__ part, long P, int C) {
+                                                              float* __restrict__ part, long P, int C, float* __restrict__ wpart) {
     __shared__ float red[2][256][9];
     const int G = C >> 3;
     const long gt = (long)blockIdx.x * 256 + threadIdx.x;
     const int cg = (int)(gt % G);                            // (256 % G == 0: the same for every trip of this thread)
     const long stride_p = ((long)gridDim.x * 256) / G;
-    float w[NC][8];
+    float w[NC][8], wacc[NC][8];
     float4 t[8];
     float rs[8], s[8], q[8];
 #pragma unroll
@@ -360,6 +362,8 @@ __global__ __launch_bounds__(256) void smallk1x1_bnred_kernel(const half_t* __re
         t[j] = txbn[cg * 8 + j];
         rs[j] = rstd[cg * 8 + j];
         s[j] = q[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) wacc[k][j] = 0.f;
 #pragma unroll
         for (int k = 0; k < NC; ++k) w[k][j] = (float)wp[k * C + cg * 8 + j];
     }
@@ -379,6 +383,11 @@ __global__ __launch_bounds__(256) void smallk1x1_bnred_kernel(const half_t* __re
             const float dz = umi_tx_pre(yy, t[j]) > t[j].w ? (float)o[j] : 0.f;
             s[j] += dz;
             q[j] = fmaf(dz, (yy - t[j].x) * rs[j], q[j]);
+            if (wpart) {
+                const float av = umi_tx(yy, t[j]);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) wacc[k][j] = fmaf(av, d[k], wacc[k][j]);
+            }
         }
         *reinterpret_cast<half8*>(y + p * ldy + cg * 8) = o;
     }
@@ -390,6 +399,19 @@ __global__ __launch_bounds__(256) void smallk1x1_bnred_kernel(const half_t* __re
         float a = 0.f;
         for (int k = 0; k < 256 / G; ++k) a += red[which][k * G + (c >> 3)][c & 7];
         part[((long)blockIdx.x * 2 + which) * C + c] = a;
+    }
+    if (wpart) {
+        for (int k = 0; k < NC; ++k) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[0][threadIdx.x][j] = wacc[k][j];
+            __syncthreads();
+            if ((int)threadIdx.x < C) {
+                float a = 0.f;
+                for (int qq = 0; qq < 256 / G; ++qq) a += red[0][qq * G + (threadIdx.x >> 3)][threadIdx.x & 7];
+                wpart[((long)blockIdx.x * C + threadIdx.x) * NC + k] = a;
+            }
+        }
     }
 }
 
@@ -435,6 +457,23 @@ __global__ __launch_bounds__(256) void head1x1_wgrad_kernel(const half_t* __rest
             part[((long)blockIdx.x * C + tid) * NC + k] = s;
         }
     }
+}
+
+// wpart[rows][C][NC] -> dW[k * s_co + c * s_ci]: one workgroup per element, fp64 accumulation (thousands of rows x 128 elements: the
+// generic split-K reduction, 4 workgroups of 8 split lanes there, took 365 us for it)
+__global__ __launch_bounds__(256) void head_wpart_reduce_kernel(const float* __restrict__ wpart, int rows, int C, int NC,
+                                                                float* __restrict__ dW, long s_co, long s_ci, float scale) {
+    __shared__ double sh[256];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    double a = 0.0;
+    for (int r = tid; r < rows; r += 256) a += (double)wpart[(long)r * C * NC + e];
+    sh[tid] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) dW[(e % NC) * s_co + (e / NC) * s_ci] = (float)(sh[0] * (double)scale);
 }
 
 int grid_for(long items) {
@@ -553,15 +592,27 @@ int umi_smallk_fwd(const void* x, int ldx, const void* wp, void* y, int ldy, lon
 }
 
 int umi_smallk_bnred_rows(long P, int Co) { return grid_for(P * (Co / 8)); }
+// dW != NULL: also the head's weight gradient dW[k * s_co + c * s_ci] = out_scale * sum_p tx(ybn[p][c]) * x[p][k]; ws >= rows * Co * Ci floats
 int umi_smallk_fwd_bnred(const void* x, int ldx, const void* wp, void* y, int ldy, const void* ybn, int ldybn, const void* txbn,
-                         const float* rstd, float* part, long P, int Ci, int Co, hipStream_t s) {
+                         const float* rstd, float* part, long P, int Ci, int Co, hipStream_t s, float* dW, long s_co, long s_ci,
+                         float out_scale, void* ws, size_t ws_bytes) {
     if (!al16(y) || !al16(ybn)) return UMI_ERR_BADARG;
     int grid = grid_for(P * (Co / 8));
-#define GO(NC) hipLaunchKernelGGL(smallk1x1_bnred_kernel<NC>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const half_t*)wp, (half_t*)y, ldy, (const half_t*)ybn, ldybn, (const float4*)txbn, rstd, part, P, Co)
+    float* wpart = nullptr;
+    if (dW) {
+        if (!ws || ws_bytes < (size_t)grid * Co * Ci * sizeof(float) || Co > 256) return UMI_ERR_WORKSPACE;
+        wpart = (float*)ws;
+    }
+#define GO(NC) hipLaunchKernelGGL(smallk1x1_bnred_kernel<NC>, dim3(grid), dim3(256), 0, s, (const half_t*)x, ldx, (const half_t*)wp, (half_t*)y, ldy, (const half_t*)ybn, ldybn, (const float4*)txbn, rstd, part, P, Co, wpart)
     switch (Ci) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
                   case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); }
 #undef GO
     UMI_LAUNCH_CHECK();
+    if (dW) {      // (kernel roles: the head conv's input channels = this kernel's Co, its output channels = Ci)
+        hipLaunchKernelGGL(head_wpart_reduce_kernel, dim3(Co * Ci), dim3(256), 0, s, (const float*)wpart, grid, Co, Ci, dW, s_co, s_ci,
+                           out_scale);
+        UMI_LAUNCH_CHECK();
+    }
     return UMI_OK;
 }
 

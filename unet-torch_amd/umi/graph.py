@@ -366,25 +366,34 @@ class Tape:
                 inv = self.inv
                 g = o.grad
                 gw = self._new_pgrad(weight)
-                ops.conv_wgrad(a.raw, a.tx, g, None, gw, Ci * R * S, R * S, 1, inv, R, S, 1, pad,
-                               defer=self._defer_list(weight, gw))
+                dx, part, fused_w = None, None, False
+                if (_wants_grad(a) and (R, S, pad) == (1, 1, 0) and _fuse_bnred() and os.environ.get("UMI_NO_HEAD_BNRED") != "1"
+                        and a.grad is None and a.parts is None and a.bn_rstd is not None and a.tx is not None
+                        and self.dtype == torch.float16 and g.dtype == torch.float16):
+                    # the head's data gradient is the only contribution to the last DoubleConv's gradient: stage 1 of that layer's
+                    # BatchNorm backward rides on it, and so does the head's own weight gradient (its input is the activated tensor
+                    # the kernel reads for the reduction): one pass over the 537 MB tensors at the bench shape instead of three
+                    dx = self.alloc(N, H, W, Ci, device=out.device)
+                    wf = weight.detach().float()
+                    want_w = os.environ.get("UMI_NO_HEAD_WGRAD_FUSION") != "1"
+                    part = ops.head_dgrad_bnred(g, self._pack("conv_dgrad", weight, wf, False), dx, a.raw, a.tx, a.bn_rstd,
+                                                dW=gw if want_w else None, out_scale=inv)
+                    fused_w = part is not None and want_w
+                if not fused_w:
+                    ops.conv_wgrad(a.raw, a.tx, g, None, gw, Ci * R * S, R * S, 1, inv, R, S, 1, pad,
+                                   defer=self._defer_list(weight, gw))
                 self._set_pgrad(weight, gw)
                 if bias is not None:
                     gb = self._new_pgrad(bias)
                     ops.colsum(g, gb, inv)
                     self._set_pgrad(bias, gb)
                 if _wants_grad(a):
-                    dx = self.alloc(N, H, W, Ci, device=out.device)
-                    wf = weight.detach().float()
-                    part = None
-                    if ((R, S, pad) == (1, 1, 0) and _fuse_bnred() and os.environ.get("UMI_NO_HEAD_BNRED") != "1" and a.grad is None and a.parts is None and a.bn_rstd is not None
-                            and a.tx is not None and self.dtype == torch.float16 and g.dtype == torch.float16):
-                        # the head's data gradient is the only contribution to the last DoubleConv's gradient: stage 1 of that
-                        # layer's BatchNorm backward rides on it (a pass over 2 x 537 MB at the bench shape otherwise)
-                        part = ops.head_dgrad_bnred(g, self._pack("conv_dgrad", weight, wf, False), dx, a.raw, a.tx, a.bn_rstd)
+                    if dx is None:
+                        dx = self.alloc(N, H, W, Ci, device=out.device)
                     if part is not None:
                         a.bn_part, a.bn_part_at = part, a.gives + 1
                     else:
+                        wf = weight.detach().float()
                         ops.conv_fwd(g, None, lambda lay: self._pack("conv_dgrad", weight, wf, bool(lay)), None, dx,
                                      R, S, 1, R - 1 - pad)
                     self._give(a, dx)

@@ -120,6 +120,9 @@ SIGNATURES = {
     "umi_conv_gather_bnred_rows": (c_int, [c_int] * 15),
     "umi_conv_gather_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
                               + [c_int] * 13 + [c_void_p]),
+    "umi_head_bwd_fused_ws_bytes": (c_size_t, [c_long, c_int, c_int]),
+    "umi_head_bwd_fused": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_long, c_long, c_float, c_void_p, c_size_t, c_long, c_int, c_int, c_int, c_void_p]),
     "umi_head_dgrad_bnred_rows": (c_int, [c_long, c_int, c_int, c_int, c_int]),
     "umi_head_dgrad_bnred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_long, c_int, c_int, c_int, c_void_p]),

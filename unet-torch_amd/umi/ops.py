@@ -590,10 +590,11 @@ def conv_gather_bnred(x, wp8, y, ybn, txbn, rstd, R, S, stride, pad, flags=0):
     return part
 
 
-def head_dgrad_bnred(dl, wp, da, ybn, txbn, rstd):
+def head_dgrad_bnred(dl, wp, da, ybn, txbn, rstd, dW=None, out_scale=1.0):
     """Data gradient of a narrow pointwise conv (OutConv: <= 8 logit channels) that also emits stage 1 of the BatchNorm backward
     reduction of the layer `da` belongs to (umi_head_dgrad_bnred).  Returns the partial-sum tensor, or None when the shape is not
-    taken (nothing was launched).  `wp`: the generic [1][Ci][Co] packing of the transposed weight."""
+    taken (nothing was launched).  `wp`: the generic [1][Ci][Co] packing of the transposed weight.
+    dW ([logit channels][feature channels][1][1] fp32): the head's weight gradient from the same pass (umi_head_bwd_fused)."""
     N, H, W, Ci, lddl = _nhwc(dl)
     _, _, _, Co, ldda = _nhwc(da)
     ldybn = _nhwc(ybn)[4]
@@ -604,6 +605,16 @@ def head_dgrad_bnred(dl, wp, da, ybn, txbn, rstd):
     if rows <= 0:
         return None
     part = torch.empty(rows * 2 * Co, dtype=torch.float32, device=dl.device)
+    if dW is not None:
+        assert dW.dtype == torch.float32 and dW.is_contiguous() and dW.numel() == Ci * Co
+        ws = workspace(L.fn("umi_head_bwd_fused_ws_bytes")(P, Ci, Co), dl.device)
+        st = L.fn("umi_head_bwd_fused")(dl.data_ptr(), lddl, wp.data_ptr(), da.data_ptr(), ldda, ybn.data_ptr(), ldybn,
+                                        txbn.data_ptr(), rstd.data_ptr(), part.data_ptr(), dW.data_ptr(), Co, 1, out_scale,
+                                        ws.data_ptr(), ws.numel(), P, Ci, Co, _dt(dl), _stream())
+        if st == -2:
+            return None
+        L.check(st, "umi_head_bwd_fused")
+        return part
     st = L.fn("umi_head_dgrad_bnred")(dl.data_ptr(), lddl, wp.data_ptr(), da.data_ptr(), ldda, ybn.data_ptr(), ldybn,
                                       txbn.data_ptr(), rstd.data_ptr(), part.data_ptr(), P, Ci, Co, _dt(dl), _stream())
     if st == -2:
