@@ -33,9 +33,10 @@ def _fuse_bnapply(Ci):
     """Stage 3 of a conv's BatchNorm backward inside its weight-gradient kernel?  Every input-channel tile (64) of that kernel
     repeats the elementwise work on the gradient tile it stages, so the fusion only pays with a single tile: measured per
     layer at the bench shapes (tools/experiments/ab_bnapply.py, profiles/r02_wgrad_bnapply_ab.txt) -0.06..-0.09 ms at Ci = 64,
-    +0.03..+0.24 ms from Ci = 128 up.  UMI_BNAPPLY_FUSION=0 / all: never / wherever the kernel applies (A-B knob)."""
+    +0.03..+0.24 ms from Ci = 128 up.  UMI_BNAPPLY_FUSION=0 / all: never / wherever the kernel applies, UMI_BNAPPLY_MAXCI=n: up to n
+    input channels (A-B knobs; round 3, whole step on one box: 64 -> 23.19 ms, 128 -> 23.26 ms, all -> +1.3 ms)."""
     mode = os.environ.get("UMI_BNAPPLY_FUSION", "")
-    return mode != "0" and (Ci <= 64 or mode == "all")
+    return mode != "0" and (Ci <= int(os.environ.get("UMI_BNAPPLY_MAXCI", "64")) or mode == "all")
 
 
 class Act:
