@@ -341,6 +341,57 @@ def test_colsum_paths(M, C, pad):
     assert (out.cpu().double() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,C", [(8192, 64), (4096, 128), (1000, 40), (513, 200), (300, 64), (64, 1024), (20000, 64)])
+def test_bn_finalize_row_reduction_forms(rows, C):
+    """BatchNorm statistics finalize over partial rows: the one-workgroup-per-channel form (< 512 rows), the 2-D form whose last
+    workgroup per channel block finishes (ragged last slice / last channel block) and the size fallback, against a float64
+    reduction; eleven launches (more than the scratch regions) are bit-identical, i.e. the counters reset themselves and the
+    summation order does not depend on which workgroup finishes last."""
+    lib, ops = _gpu()
+    g = torch.Generator().manual_seed(rows + C)
+    part = torch.randn(rows, 2, C, generator=g)
+    part[:, 1] = part[:, 1].abs() * 3 + part[:, 0] ** 2
+    count = float(rows * 7)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    mean = part[:, 0].double().sum(0) / count
+    var = (part[:, 1].double().sum(0) / count - mean * mean).clamp_min(0)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    pd, gd, bd = part.to(DEV).contiguous().view(-1), gamma.to(DEV), beta.to(DEV)
+    outs = []
+    for _ in range(11):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        tx, rs = ops.bn_finalize(pd, C, count, gd, bd, 1e-5, 0.1, rm, rv)
+        outs.append((tx.cpu(), rs.cpu(), rm.cpu(), rv.cpu()))
+    tx, rs, rm, rv = outs[0]
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+    scale = gamma.double() * rstd
+    assert (tx[:, 0].double() - mean).abs().max().item() < 1e-6 * max(1.0, mean.abs().max().item())
+    assert (tx[:, 1].double() - scale).abs().max().item() < 2e-6 * scale.abs().max().item()
+    assert (tx[:, 2].double() - (beta.double() - mean * scale)).abs().max().item() < 1e-5
+    assert (rs.double() - rstd).abs().max().item() < 2e-6 * rstd.abs().max().item()
+    assert (rm.double() - 0.1 * mean).abs().max().item() < 1e-6
+    assert (rv.double() - (0.9 + 0.1 * var * count / (count - 1))).abs().max().item() < 1e-5 * max(1.0, var.max().item())
+
+
+@pytest.mark.parametrize("M,C", [(16 * 256 * 256, 64), (70000, 24)])
+def test_bn_backward_reduce_many_rows(M, C):
+    """Both stages of the BatchNorm backward reduction with many partial rows against float64."""
+    lib, ops = _gpu()
+    g = torch.Generator().manual_seed(C)
+    y = torch.randn(1, 1, M, C, generator=g).half()
+    da = torch.randn(1, 1, M, C, generator=g).half()
+    t = _tx(C, g)
+    rstd = (0.5 + torch.rand(C, generator=g))
+    z = y.double() * t[:, 1].double() + t[:, 2].double()
+    dz = torch.where(z > 0, da.double(), torch.zeros((), dtype=torch.float64))
+    xhat = (y.double() - t[:, 0].double()) * rstd.double()
+    ref0, ref1 = dz.sum((0, 1, 2)), (dz * xhat).sum((0, 1, 2))
+    s0, s1 = ops.bn_bwd(da.to(DEV), y.to(DEV), t.to(DEV), rstd.to(DEV), apply=False)
+    assert (s0.cpu().double() - ref0).abs().max().item() < 1e-4 * max(1.0, ref0.abs().max().item())
+    assert (s1.cpu().double() - ref1).abs().max().item() < 1e-4 * max(1.0, ref1.abs().max().item())
+
+
 # ---- multi-tensor optimizer step and weight re-pack (SURVEY 8(f) rank 2) ---------------------------------------------
 def _param_set(gen):
     """Tensors of very unequal sizes, incl. odd lengths and 4-byte-aligned views (flat-bucket slices)."""

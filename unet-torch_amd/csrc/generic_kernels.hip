@@ -255,7 +255,127 @@ int umi_conv_fwd_generic(const void* x, int ldx, const void* tx, const void* wp,
 }
 
 // ------------------------------------------------------------------------------------------
-// BatchNorm statistics finalize: one block per channel, fixed-order double reduction.
+// Partial-row reductions part[rows][2][C] -> per-channel totals, two forms:
+//   * few rows: one workgroup per channel (column-strided reads; the rows are few, the launch is latency-bound anyway);
+//   * many rows (the 512 x 512 / 256 x 256 layers write 4,096-8,192 partial rows = 4 MB: the one-workgroup-per-channel form
+//     spent 28 us on it, 64-128 workgroups each pulling a whole line per 4-byte element): a 2-D grid of (32-channel block,
+//     64-row slice) workgroups reads whole 128-byte runs, every slice leaves one double per column in a scratch row, and the
+//     LAST workgroup of a channel block to finish (a counter per block; agent-scope stores / loads of the scratch rows) adds the slice
+//     rows in slice order and finalizes.  The order of every addition is fixed by the indices, never by arrival, so the
+//     totals are run-to-run identical (the counter only picks WHO does the final pass).
+// The scratch rows and counters are static device memory (nothing is allocated at launch time: safe under graph capture),
+// dealt round-robin over RED_REGIONS regions: launches on one stream serialize anyway; up to RED_REGIONS launches may run
+// concurrently on different streams.
+// ------------------------------------------------------------------------------------------
+constexpr int RED_RPS = 128;             // rows per slice (two batches of 16 per wave)
+constexpr int RED_MAX_SLICES = 1024;     // (channel block, slice) pairs of one launch: rows x C <= 2 M
+constexpr int RED_MAX_CB = 64;           // <= 2,048 channels
+constexpr int RED_REGIONS = 8;
+constexpr int RED_MIN_ROWS = 512;        // below this the one-workgroup-per-channel form is as fast
+__device__ double g_red_scratch[RED_REGIONS][RED_MAX_SLICES * 64];       // [region][(cb * nslices + slice) * 64 + lane]: 4 MB
+__device__ unsigned g_red_count[RED_REGIONS][RED_MAX_CB];
+
+static bool red2d_ok(int rows, int C) {
+    const int nslices = (rows + RED_RPS - 1) / RED_RPS, ncb = (C + 31) / 32;
+    return rows >= RED_MIN_ROWS && ncb <= RED_MAX_CB && (long)ncb * nslices <= RED_MAX_SLICES;
+}
+static int red2d_region() {
+    static unsigned turn = 0;
+    return (int)(turn++ % RED_REGIONS);
+}
+
+// Column sums of a 32-channel block: lanes 0..31 = column 0 (sums) of channels c0 + lane, lanes 32..63 = column 1 of the same
+// channels.  Returns true in wave 0 of the workgroup that holds the block's totals (`tot`, valid where c < C).
+__device__ __forceinline__ bool red2d_block(const float* __restrict__ part, int rows, int C, bool two, int region, double& tot) {
+    __shared__ double sh[4][64];
+    __shared__ unsigned is_last;
+    const int cb = blockIdx.x, slice = blockIdx.y, nslices = gridDim.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = cb * 32 + (lane & 31), which = lane >> 5;
+    const bool live = c < C && (two || which == 0);
+    const int csel = c < C ? c : C - 1, wsel = two ? which : 0;
+    double a = 0.0;
+#pragma unroll
+    for (int b = 0; b < RED_RPS / 64; ++b) {               // batches of 16 rows per wave, all 16 loads in flight
+        const int r0 = slice * RED_RPS + b * 64 + wave;
+        float v[16];
+        // (unconditional loads from clamped addresses, all 16 issued before the first is touched, then a select: hipcc turns a
+        //  predicated load into a branch with a wait of its own, and sinks a plain one back under the predicate)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + 4 * i, rc = r < rows ? r : rows - 1;
+            v[i] = part[((long)rc * 2 + wsel) * C + csel];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(v[i]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (live && r0 + 4 * i < rows) ? v[i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += (double)v[i];
+    }
+    sh[wave][lane] = a;
+    __syncthreads();
+    a = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+    if (nslices == 1) { tot = a; return wave == 0; }
+    double* scr = g_red_scratch[region] + ((long)cb * nslices) * 64;
+    if (wave == 0) {
+        // The slice row leaves as agent-scope (write-through) stores and is complete -- vmcnt(0) -- before this wave's count:
+        // a full release fence here would write back the XCD's whole L2 once per workgroup (measured: 22 us for the
+        // 8,192-row case, more than the column-strided kernel it replaces on the smaller ones).  The finishing workgroup
+        // reads the rows with agent-scope loads, which do not hit in a stale line of its own L2.
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(scr + (long)slice * 64 + lane),
+                           __builtin_bit_cast(unsigned long long, a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            is_last = __hip_atomic_fetch_add(&g_red_count[region][cb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                              (unsigned)nslices - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return false;
+    // the finishing workgroup: wave w adds slices w, w + 4, ... in that order (plain loads, 8 in flight), then the four
+    // wave sums are added in wave order -- fixed by the indices, whoever finishes last
+    double t = 0.0;
+    for (int s0 = wave; s0 < nslices; s0 += 32) {
+        double u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            u[i] = s0 + 4 * i < nslices
+                       ? __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(scr + (long)(s0 + 4 * i) * 64 + lane),
+                                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                       : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += u[i];
+    }
+    __syncthreads();                                       // (sh is read above by every wave)
+    sh[wave][lane] = t;
+    __syncthreads();
+    if (wave != 0) return false;
+    tot = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+    if (lane == 0) __hip_atomic_store(&g_red_count[region][cb], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch that draws this region
+    return true;
+}
+
+// the per-channel arithmetic of the BatchNorm statistics finalize (both forms)
+__device__ __forceinline__ void bn_finalize_channel(int c, double sum, double sumsq, double count, const float* gamma,
+                                                    const float* beta, float eps, float momentum, float* rmean, float* rvar,
+                                                    float4* tx_out, float* rstd_out) {
+    double mean = sum / count;
+    double var = sumsq / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double rstd = 1.0 / sqrt(var + (double)eps);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const double scale = (double)g * rstd;
+    tx_out[c] = make_float4((float)mean, (float)scale, (float)((double)b - mean * scale), 0.f);
+    if (rstd_out) rstd_out[c] = (float)rstd;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    if (rvar) {
+        double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm statistics finalize: fixed-order double reduction (one block per channel, or the 2-D form above).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -265,9 +385,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __shared__ double sh[2][256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int r = tid; r < rows; r += 256) {
-        s += (double)part[((long)r * 2 + 0) * C + c];
-        q += (double)part[((long)r * 2 + 1) * C + c];
+    // a thread's rows are a line apart each: the launch is bound by load round trips, so 8 rows (16 loads) are in flight per
+    // trip (clamped address + select: no branch around a load); the additions keep their row order (same sums as a plain loop)
+    for (int r0 = tid; r0 < rows; r0 += 256 * 8) {
+        float vs[8], vq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = r0 + 256 * i, rc = r < rows ? r : rows - 1;
+            vs[i] = part[((long)rc * 2 + 0) * C + c];
+            vq[i] = part[((long)rc * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(vs[i]), "+v"(vq[i]));      // (all 16 loads issued; none sunk under a predicate)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const bool ok = r0 + 256 * i < rows; vs[i] = ok ? vs[i] : 0.f; vq[i] = ok ? vq[i] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s += (double)vs[i]; q += (double)vq[i]; }
     }
     sh[0][tid] = s;
     sh[1][tid] = q;
@@ -276,29 +409,34 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
         __syncthreads();
     }
-    if (tid == 0) {
-        double mean = sh[0][0] / count;
-        double var = sh[1][0] / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        double rstd = 1.0 / sqrt(var + (double)eps);
-        float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-        const double scale = (double)g * rstd;
-        tx_out[c] = make_float4((float)mean, (float)scale, (float)((double)b - mean * scale), 0.f);
-        if (rstd_out) rstd_out[c] = (float)rstd;
-        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-        if (rvar) {
-            double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-        }
-    }
+    if (tid == 0) bn_finalize_channel(c, sh[0][0], sh[1][0], count, gamma, beta, eps, momentum, rmean, rvar, tx_out, rstd_out);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize2d_kernel(const float* __restrict__ part, int rows, int C, double count,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, float momentum, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, float4* __restrict__ tx_out,
+                                                            float* __restrict__ rstd_out, int region) {
+    double tot = 0.0;
+    if (!red2d_block(part, rows, C, true, region, tot)) return;
+    // wave 0 of the finishing workgroup: lane l < 32 holds channel c's sum, lane l + 32 its sum of squares
+    const int lane = threadIdx.x & 63;
+    const double q = __shfl(tot, (lane & 31) + 32, 64);
+    const int c = blockIdx.x * 32 + lane;
+    if (lane < 32 && c < C) bn_finalize_channel(c, tot, q, count, gamma, beta, eps, momentum, rmean, rvar, tx_out, rstd_out);
 }
 
 extern "C" int umi_bn_finalize(const float* stat_part, int rows, int C, double count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                void* tx_out, float* rstd_out, umi_stream_t stream) {
     if (!stat_part || !tx_out || rows <= 0 || C <= 0 || count <= 0) return UMI_ERR_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, rows, C, count, gamma,
-                       beta, eps, momentum, running_mean, running_var, (float4*)tx_out, rstd_out);
+    if (red2d_ok(rows, C))
+        hipLaunchKernelGGL(bn_finalize2d_kernel, dim3((C + 31) / 32, (rows + RED_RPS - 1) / RED_RPS), dim3(256), 0,
+                           (hipStream_t)stream, stat_part, rows, C, count, gamma, beta, eps, momentum, running_mean,
+                           running_var, (float4*)tx_out, rstd_out, red2d_region());
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stat_part, rows, C, count, gamma,
+                           beta, eps, momentum, running_mean, running_var, (float4*)tx_out, rstd_out);
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }
@@ -469,9 +607,21 @@ __global__ __launch_bounds__(256) void reduce_rows2_kernel(const float* __restri
     __shared__ double sh[2][256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int r = tid; r < rows; r += 256) {
-        s += (double)ws[((long)r * 2 + 0) * C + c];
-        if (out1) q += (double)ws[((long)r * 2 + 1) * C + c];
+    const int w1 = out1 ? 1 : 0;                            // (without a second output the second column is not read: same address twice)
+    for (int r0 = tid; r0 < rows; r0 += 256 * 8) {          // 8 rows in flight per trip, additions in row order (see bn_finalize_kernel)
+        float vs[8], vq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = r0 + 256 * i, rc = r < rows ? r : rows - 1;
+            vs[i] = ws[((long)rc * 2 + 0) * C + c];
+            vq[i] = ws[((long)rc * 2 + w1) * C + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(vs[i]), "+v"(vq[i]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const bool ok = r0 + 256 * i < rows; vs[i] = ok ? vs[i] : 0.f; vq[i] = (ok && out1) ? vq[i] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s += (double)vs[i]; q += (double)vq[i]; }
     }
     sh[0][tid] = s;
     sh[1][tid] = q;
@@ -486,8 +636,24 @@ __global__ __launch_bounds__(256) void reduce_rows2_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void reduce_rows2_2d_kernel(const float* __restrict__ ws, int rows, int C,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              float scale, int region) {
+    double tot = 0.0;
+    if (!red2d_block(ws, rows, C, out1 != nullptr, region, tot)) return;
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 32 + (lane & 31);
+    if (c < C) {
+        if (lane < 32) out0[c] = (float)(tot * (double)scale);
+        else if (out1) out1[c] = (float)(tot * (double)scale);
+    }
+}
+
 void umi_launch_reduce_rows2(const float* ws, int rows, int C, float* out0, float* out1, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, ws, rows, C, out0, out1, scale);
+    if (red2d_ok(rows, C))
+        hipLaunchKernelGGL(reduce_rows2_2d_kernel, dim3((C + 31) / 32, (rows + RED_RPS - 1) / RED_RPS), dim3(256), 0, s, ws,
+                           rows, C, out0, out1, scale, red2d_region());
+    else
+        hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, ws, rows, C, out0, out1, scale);
 }
 
 template <typename T>
@@ -520,7 +686,7 @@ extern "C" int umi_bn_bwd_reduce(const void* da, int ldda, const void* y, int ld
     if (dtype == UMI_F16 && umi_bn_bwd_reduce1_f16v(da, ldda, y, ldy, tx, rstd, (float*)ws, M, C, s)) {
         UMI_LAUNCH_CHECK();
         rows = umi_cdiv(M, umi_bn_bwd_rpb_f16v(M));
-        hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, rows, C, sum_dz, sum_dzx, 1.f);
+        umi_launch_reduce_rows2((const float*)ws, rows, C, sum_dz, sum_dzx, 1.f, s);
         UMI_LAUNCH_CHECK();
         return UMI_OK;
     }
@@ -528,7 +694,7 @@ extern "C" int umi_bn_bwd_reduce(const void* da, int ldda, const void* y, int ld
     else if (dtype == UMI_F16) hipLaunchKernelGGL(bn_bwd_reduce1_kernel<half_t>, dim3(rows), dim3(256), 0, s, (const half_t*)da, ldda, (const half_t*)y, ldy, (const float4*)tx, rstd, (float*)ws, M, C);
     else return UMI_ERR_BADARG;
     UMI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, rows, C, sum_dz, sum_dzx, 1.f);
+    umi_launch_reduce_rows2((const float*)ws, rows, C, sum_dz, sum_dzx, 1.f, s);
     UMI_LAUNCH_CHECK();
     return UMI_OK;
 }
@@ -634,8 +800,7 @@ extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, l
     hipStream_t s = (hipStream_t)stream;
     if (dtype == UMI_F16 && umi_colsum_f16v(x, ldx, (float*)ws, M, C, s)) {
         UMI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, umi_colsum_rows_f16v(M, C), C, out,
-                           (float*)nullptr, out_scale);
+        umi_launch_reduce_rows2((const float*)ws, umi_colsum_rows_f16v(M, C), C, out, (float*)nullptr, out_scale, s);
         UMI_LAUNCH_CHECK();
         return UMI_OK;
     }
@@ -647,8 +812,7 @@ extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, l
         float* tmp = (float*)ws + (size_t)umi_colsum_rows_f16v(M8, 8) * 2 * 8;
         if (umi_colsum_f16v(x, 8, (float*)ws, M8, 8, s)) {
             UMI_LAUNCH_CHECK();
-            hipLaunchKernelGGL(reduce_rows2_kernel, dim3(8), dim3(256), 0, s, (const float*)ws, umi_colsum_rows_f16v(M8, 8), 8, tmp,
-                               (float*)nullptr, 1.f);
+            umi_launch_reduce_rows2((const float*)ws, umi_colsum_rows_f16v(M8, 8), 8, tmp, (float*)nullptr, 1.f, s);
             hipLaunchKernelGGL(fold_cols_kernel, dim3(1), dim3(64), 0, s, (const float*)tmp, C, out, out_scale);
             UMI_LAUNCH_CHECK();
             return UMI_OK;
@@ -660,7 +824,7 @@ extern "C" int umi_colsum(const void* x, int ldx, float* out, float out_scale, l
     else return UMI_ERR_BADARG;
     UMI_LAUNCH_CHECK();
     if (splits > 1) {
-        hipLaunchKernelGGL(reduce_rows2_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, splits, C, out, (float*)nullptr, out_scale);
+        umi_launch_reduce_rows2((const float*)ws, splits, C, out, (float*)nullptr, out_scale, s);
         UMI_LAUNCH_CHECK();
     }
     return UMI_OK;

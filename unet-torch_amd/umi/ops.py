@@ -65,10 +65,11 @@ _passthrough = {}
 
 def passthrough_tx_const(C, device):
     """The same rows as a shared constant, built once per (C, device): for callers that only read / concatenate them."""
-    if torch.cuda.is_current_stream_capturing():
-        return passthrough_tx(C, device)               # not cached: would live in the graph's private pool
     key = (C, str(device))
     t = _passthrough.get(key)
+    if t is None and torch.cuda.is_current_stream_capturing():
+        return passthrough_tx(C, device)               # not cached: would live in the graph's private pool
+    # (a constant built by an eager warm-up step is ordinary memory and is what a later capture reads: 3 launches per use less)
     if t is None:
         t = _passthrough[key] = passthrough_tx(C, device)
     return t
