@@ -172,3 +172,79 @@ def test_pointwise_gemm_is_exact_on_integer_data(case):
     assert ops.conv_plan(xd, y, 1, 1, 1, 0, 0, True)[0] == 1
     ops.conv_fwd(xd, None, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), b.to(DEV), y, 1, 1, 1, 0)
     assert torch.equal(y.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("cin", [1, 3])
+def test_stem_and_head_are_exact_on_integer_data(cin):
+    """First conv (Ci <= 4: forward, statistics, weight gradient) and the OutConv head (fp32 logits with bias, data and weight
+    gradient) -- the narrow kernels around the MFMA trunk (csrc/stem_head.hip)."""
+    lib, ops = _gpu()
+    N, H, W, C, ncls = 2, 37, 29, 64, 2 if cin == 1 else 4
+    g = torch.Generator().manual_seed(10 + cin)
+    x = _ints((N, H, W, cin), -3, 3, g)
+    w = _ints((C, cin, 3, 3), -2, 2, g)
+    dy = _ints((N, H, W, C), -1, 1, g)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), wr, None, 1, 1)
+    ref.backward(dy.permute(0, 3, 1, 2))
+    ref = ref.detach().permute(0, 2, 3, 1).contiguous()
+    xd, wd = x.half().to(DEV), w.to(DEV)
+    y = torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+    part = ops.conv_fwd(xd, None, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), None, y, 3, 3, 1, 1, want_stats=True)
+    gw = torch.empty(C, cin, 3, 3, device=DEV)
+    ops.conv_wgrad(xd, None, dy.half().to(DEV), None, gw, cin * 9, 9, 1, 0.25, 3, 3, 1, 1)
+    assert torch.equal(y.float().cpu(), ref)
+    s = part.view(-1, 2, C).sum(0).cpu()
+    assert torch.equal(s[0], ref.sum((0, 1, 2))) and torch.equal(s[1], (ref * ref).sum((0, 1, 2)))
+    assert torch.equal(gw.cpu(), wr.grad * 0.25)
+
+    a = _ints((N, H, W, C), -2, 2, g)
+    t = _int_tx(C, g)
+    wo = _ints((ncls, C, 1, 1), -2, 2, g)
+    b = _ints((ncls,), -3, 3, g)
+    dl = _ints((N, H, W, ncls), -2, 2, g)
+    act = _apply(a, t).permute(0, 3, 1, 2).requires_grad_(True)
+    wor = wo.clone().requires_grad_(True)
+    out = F.conv2d(act, wor, b)
+    out.backward(dl.permute(0, 3, 1, 2))
+    ad, td, wod, dld = a.half().to(DEV), t.to(DEV), wo.to(DEV), dl.half().to(DEV)
+    logits = torch.empty(N, H, W, ncls, device=DEV, dtype=torch.float32)
+    ops.conv_fwd(ad, td, lambda l: ops.pack_conv_fwd(wod, torch.float16, k8=bool(l)), b.to(DEV), logits, 1, 1, 1, 0)
+    da = torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+    ops.conv_fwd(dld, None, lambda l: ops.pack_conv_dgrad(wod, torch.float16, k8=bool(l)), None, da, 1, 1, 1, 0)
+    gwo = torch.empty(ncls, C, 1, 1, device=DEV)
+    ops.conv_wgrad(ad, td, dld, None, gwo, C, 1, 1, 2.0, 1, 1, 1, 0)
+    assert torch.equal(logits.cpu(), out.detach().permute(0, 2, 3, 1))
+    assert torch.equal(da.float().cpu(), act.grad.permute(0, 2, 3, 1))
+    assert torch.equal(gwo.cpu(), wor.grad * 2.0)
+
+
+def test_maxpool_with_transform_is_exact_on_integer_data():
+    """MaxPool2d(2) of the lazily-activated tensor (transform on load) and its backward scatter (ties: torch's first-max rule
+    is not assumed -- the data has no ties inside a window)."""
+    lib, ops = _gpu()
+    N, H, W, C = 2, 12, 20, 64
+    g = torch.Generator().manual_seed(3)
+    # distinct values inside every 2 x 2 window: a permutation of 0..3 per window, times a positive per-channel step
+    base = torch.stack([torch.randperm(4, generator=g) for _ in range(N * (H // 2) * (W // 2) * C)]).float()
+    base = base.view(N, H // 2, W // 2, C, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, H, W, C)
+    x = base + 1.0
+    t = torch.zeros(C, 4)
+    t[:, 1] = torch.tensor([1.0, 2.0])[torch.randint(0, 2, (C,), generator=g)]
+    t[:, 2] = _ints((C,), -2, 0, g)
+    act = _apply(x, t).permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.max_pool2d(act, 2)
+    dp = _ints((N, H // 2, W // 2, C), -3, 3, g)
+    ref.backward(dp.permute(0, 3, 1, 2))
+    xd, td = x.half().to(DEV), t.to(DEV)
+    y = torch.empty(N, H // 2, W // 2, C, device=DEV, dtype=torch.float16)
+    ops.pool2_fwd(xd, td, y)
+    assert torch.equal(y.float().cpu(), ref.detach().permute(0, 2, 3, 1))
+    da = torch.empty(N, H, W, C, device=DEV, dtype=torch.float16)
+    ops.pool2_bwd(dp.half().to(DEV), xd, td, da, False)
+    # windows whose activated values tie at 0 (ReLU clipped) route the gradient by convention: compare where the max is unique
+    a4 = act.detach().view(N, C, H // 2, 2, W // 2, 2)
+    mx = a4.amax((3, 5), keepdim=True)
+    unique = ((a4 == mx).sum((3, 5), keepdim=True) == 1).expand_as(a4).reshape(N, C, H, W).permute(0, 2, 3, 1)
+    assert unique.float().mean().item() > 0.5
+    assert torch.equal(da.float().cpu()[unique], act.grad.permute(0, 2, 3, 1)[unique])
