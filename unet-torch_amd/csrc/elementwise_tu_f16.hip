@@ -36,8 +36,9 @@ __global__ __launch_bounds__(256) void ew8_kernel(const half_t* __restrict__ x, 
                                                   half_t* __restrict__ y, int ldy, long M, int C8, long bcast_rows) {
     const long total = M * C8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C8) * 8;
-        const long r = i / C8;
+        long r; int c;
+        umi_divmod(i, C8, r, c);
+        c *= 8;
         half8 xv = *reinterpret_cast<const half8*>(x + r * ldx + c), gv, o;
         if (MODE == 1 || MODE == 2) gv = *reinterpret_cast<const half8*>(g + r * ldg + c);
         if (MODE == 3) gv = *reinterpret_cast<const half8*>(g + (r % bcast_rows) * ldg + c);
@@ -62,8 +63,9 @@ __global__ __launch_bounds__(256) void dropout8_kernel(const half_t* __restrict_
     const float scale = 1.f / (1.f - p);
     const int C = C8 * 8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C8) * 8;
-        const long r = i / C8;
+        long r; int c;
+        umi_divmod(i, C8, r, c);
+        c *= 8;
         const long e0 = r * C + c;                                       // element index of the scalar kernel
         half8 xv = *reinterpret_cast<const half8*>(x + r * ldx + c), o;
         unsigned long long mk = 0;
@@ -101,8 +103,9 @@ __global__ __launch_bounds__(256) void dropout8_fused_kernel(const half_t* __res
     const float scale = 1.f / (1.f - p);
     const int C = C8 * 8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C8) * 8;
-        const long r = i / C8;
+        long r; int c;
+        umi_divmod(i, C8, r, c);
+        c *= 8;
         const long e0 = r * C + c;
         half8 xv = *reinterpret_cast<const half8*>(x + r * ldx + c), av, o;
         if (AUX || (GELU && bwd)) av = *reinterpret_cast<const half8*>(aux + r * ldaux + c);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void pool3s2_bwd8_kernel(const half_t* __restr
         half8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
-        *reinterpret_cast<half8*>(dx + p * lddx + c) = o;
+        *reinterpret_cast<half8*>(dx + (long)p * lddx + c) = o;
     }
 }
 
@@ -352,17 +355,26 @@ bool umi_ln_bwd_f16v(const void* dy, int lddy, const void* x, int ldx, const flo
 // expressions as the scalar kernels in transformer_kernels.hip) ------------------------------------------------------------
 namespace {
 
+// A thread keeps ONE 8-channel group for all its pixels (256 % C8 == 0, as in pool2_fwd_v8): its transform rows are loaded once,
+// so a pixel costs four loads and a store instead of twelve loads and a store (the kernel was bound by vector-memory issue:
+// 1.2 TB/s of output); the pixel index is split with 32-bit divisions (IDX = unsigned wherever the pixel count allows).
+template <typename IDX>
 __global__ __launch_bounds__(256) void bilinear2x_fwd8_kernel(const half_t* __restrict__ x, int ldx, const float4* __restrict__ tx,
                                                               half_t* __restrict__ y, int ldy, int N, int H, int W, int C8) {
     const int Ho = 2 * H, Wo = 2 * W;
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-    const long total = (long)N * Ho * Wo * C8;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C8) * 8;
-        const long p = i / C8;
-        const int wo = (int)(p % Wo);
-        const long r = p / Wo;
-        const int ho = (int)(r % Ho), n = (int)(r / Ho);
+    const IDX gt = (IDX)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(gt % (IDX)C8) * 8;
+    const IDX stride_p = ((IDX)gridDim.x * 256) / (IDX)C8, P = (IDX)N * Ho * Wo;
+    float4 t[8];
+    if (tx) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = tx[c + j];
+    }
+    for (IDX p = gt / (IDX)C8; p < P; p += stride_p) {
+        const int wo = (int)(p % (IDX)Wo);
+        const IDX r = p / (IDX)Wo;
+        const int ho = (int)(r % (IDX)Ho), n = (int)(r / (IDX)Ho);
         const float fy = ho * sy, fx = wo * sx;
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
@@ -376,24 +388,25 @@ __global__ __launch_bounds__(256) void bilinear2x_fwd8_kernel(const half_t* __re
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v00 = (float)a00[j], v01 = (float)a01[j], v10 = (float)a10[j], v11 = (float)a11[j];
-            if (tx) { const float4 t = tx[c + j]; v00 = umi_tx(v00, t); v01 = umi_tx(v01, t); v10 = umi_tx(v10, t); v11 = umi_tx(v11, t); }
+            if (tx) { v00 = umi_tx(v00, t[j]); v01 = umi_tx(v01, t[j]); v10 = umi_tx(v10, t[j]); v11 = umi_tx(v11, t[j]); }
             o[j] = (half_t)((1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11));
         }
-        *reinterpret_cast<half8*>(y + p * ldy + c) = o;
+        *reinterpret_cast<half8*>(y + (long)p * ldy + c) = o;
     }
 }
 
+template <typename IDX>
 __global__ __launch_bounds__(256) void bilinear2x_bwd8_kernel(const half_t* __restrict__ dy, int lddy, half_t* __restrict__ dx,
                                                               int lddx, int N, int H, int W, int C8) {
     const int Ho = 2 * H, Wo = 2 * W;
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-    const long total = (long)N * H * W * C8;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C8) * 8;
-        const long p = i / C8;
-        const int w = (int)(p % W);
-        const long r = p / W;
-        const int h = (int)(r % H), n = (int)(r / H);
+    const IDX total = (IDX)N * H * W * C8;
+    for (IDX i = (IDX)blockIdx.x * 256 + threadIdx.x; i < total; i += (IDX)gridDim.x * 256) {
+        const int c = (int)(i % (IDX)C8) * 8;
+        const IDX p = i / (IDX)C8;
+        const int w = (int)(p % (IDX)W);
+        const IDX r = p / (IDX)W;
+        const int h = (int)(r % (IDX)H), n = (int)(r / (IDX)H);
         int ho_lo = sy > 0.f ? (int)floorf((h - 1) / sy) : 0, ho_hi = sy > 0.f ? (int)ceilf((h + 1) / sy) : Ho - 1;
         int wo_lo = sx > 0.f ? (int)floorf((w - 1) / sx) : 0, wo_hi = sx > 0.f ? (int)ceilf((w + 1) / sx) : Wo - 1;
         ho_lo = ho_lo < 0 ? 0 : ho_lo; wo_lo = wo_lo < 0 ? 0 : wo_lo;
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(256) void bilinear2x_bwd8_kernel(const half_t* __re
         half8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
-        *reinterpret_cast<half8*>(dx + p * lddx + c) = o;
+        *reinterpret_cast<half8*>(dx + (long)p * lddx + c) = o;
     }
 }
 
@@ -434,12 +447,23 @@ bool umi_bilinear2x_f16v(const void* x, int ldx, const void* tx, void* y, int ld
                          hipStream_t s) {
     if (C % 8 || ldx % 8 || ldy % 8 || !al16(x) || !al16(y)) return false;
     const int C8 = C / 8;
-    if (!backward)
-        hipLaunchKernelGGL(bilinear2x_fwd8_kernel, dim3(grid8((long)N * 4 * H * W * C8)), dim3(256), 0, s, (const half_t*)x, ldx,
-                           (const float4*)tx, (half_t*)y, ldy, N, H, W, C8);
-    else
-        hipLaunchKernelGGL(bilinear2x_bwd8_kernel, dim3(grid8((long)N * H * W * C8)), dim3(256), 0, s, (const half_t*)x, ldx,
-                           (half_t*)y, ldy, N, H, W, C8);
+    if (!backward && (C8 > 256 || 256 % C8)) return false;       // (forward: one channel group per thread; other widths take the scalar kernel)
+    const bool small = (long)N * 4 * H * W * C8 + 16384L * 256 < 0xFFFFFFFFL;      // (the grid-stride loop's last increment must not wrap)
+    if (!backward) {
+        if (small)
+            hipLaunchKernelGGL(bilinear2x_fwd8_kernel<unsigned>, dim3(grid8((long)N * 4 * H * W * C8)), dim3(256), 0, s, (const half_t*)x,
+                               ldx, (const float4*)tx, (half_t*)y, ldy, N, H, W, C8);
+        else
+            hipLaunchKernelGGL(bilinear2x_fwd8_kernel<long>, dim3(grid8((long)N * 4 * H * W * C8)), dim3(256), 0, s, (const half_t*)x,
+                               ldx, (const float4*)tx, (half_t*)y, ldy, N, H, W, C8);
+    } else {
+        if (small)
+            hipLaunchKernelGGL(bilinear2x_bwd8_kernel<unsigned>, dim3(grid8((long)N * H * W * C8)), dim3(256), 0, s, (const half_t*)x, ldx,
+                               (half_t*)y, ldy, N, H, W, C8);
+        else
+            hipLaunchKernelGGL(bilinear2x_bwd8_kernel<long>, dim3(grid8((long)N * H * W * C8)), dim3(256), 0, s, (const half_t*)x, ldx,
+                               (half_t*)y, ldy, N, H, W, C8);
+    }
     return true;
 }
 

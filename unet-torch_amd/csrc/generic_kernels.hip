@@ -268,11 +268,11 @@ int umi_conv_fwd_generic(const void* x, int ldx, const void* tx, const void* wp,
 // concurrently on different streams.
 // ------------------------------------------------------------------------------------------
 constexpr int RED_RPS = 128;             // rows per slice (two batches of 16 per wave)
-constexpr int RED_MAX_SLICES = 1024;     // (channel block, slice) pairs of one launch: rows x C <= 2 M
-constexpr int RED_MAX_CB = 64;           // <= 2,048 channels
-constexpr int RED_REGIONS = 8;
+constexpr int RED_MAX_SLICES = 4096;     // (channel block, slice) pairs of one launch: rows x C <= 16 M
+constexpr int RED_MAX_CB = 128;          // <= 4,096 channels (the ViT's 3,072-wide fc1 bias gradient)
+constexpr int RED_REGIONS = 4;
 constexpr int RED_MIN_ROWS = 512;        // below this the one-workgroup-per-channel form is as fast
-__device__ double g_red_scratch[RED_REGIONS][RED_MAX_SLICES * 64];       // [region][(cb * nslices + slice) * 64 + lane]: 4 MB
+__device__ double g_red_scratch[RED_REGIONS][RED_MAX_SLICES * 64];       // [region][(cb * nslices + slice) * 64 + lane]: 8 MB
 __device__ unsigned g_red_count[RED_REGIONS][RED_MAX_CB];
 
 static bool red2d_ok(int rows, int C) {
@@ -648,8 +648,26 @@ __global__ __launch_bounds__(256) void reduce_rows2_2d_kernel(const float* __res
     }
 }
 
+// few rows, very many columns (the position-embedding gradient: 24 batch rows x 150,528 columns): one THREAD per column, the
+// lanes of a wave on adjacent columns -- a workgroup per column there is 150 K workgroups of 256 threads for 24 additions each
+// (149 us against ~6 us)
+__global__ __launch_bounds__(256) void reduce_rows2_wide_kernel(const float* __restrict__ ws, int rows, int C,
+                                                                float* __restrict__ out0, float* __restrict__ out1, float scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s += (double)ws[((long)r * 2 + 0) * C + c];
+        if (out1) q += (double)ws[((long)r * 2 + 1) * C + c];
+    }
+    out0[c] = (float)(s * (double)scale);
+    if (out1) out1[c] = (float)(q * (double)scale);
+}
+
 void umi_launch_reduce_rows2(const float* ws, int rows, int C, float* out0, float* out1, float scale, hipStream_t s) {
-    if (red2d_ok(rows, C))
+    if (rows <= 64 && C >= 4096)
+        hipLaunchKernelGGL(reduce_rows2_wide_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, rows, C, out0, out1, scale);
+    else if (red2d_ok(rows, C))
         hipLaunchKernelGGL(reduce_rows2_2d_kernel, dim3((C + 31) / 32, (rows + RED_RPS - 1) / RED_RPS), dim3(256), 0, s, ws,
                            rows, C, out0, out1, scale, red2d_region());
     else

@@ -153,6 +153,7 @@ __device__ void pack_tiles_k8(const PackDesc& d, int my_blk, int n_blk) {
         for (int e0 = threadIdx.x; e0 < PT * PT * TT; e0 += 1024) {
             float v[4];
             int li[4];
+            bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + 256 * u;
@@ -160,10 +161,17 @@ __device__ void pack_tiles_k8(const PackDesc& d, int my_blk, int n_blk) {
                 const int i_ = r / TT, t = r - i_ * TT;
                 const int kl = k_inner ? i_ : o_, nl = k_inner ? o_ : i_;
                 const int k = k0 + kl, n = n0 + nl;
-                const bool ok = e < PT * PT * TT && k < d.K && n < d.N;
+                ok[u] = e < PT * PT * TT && k < d.K && n < d.N;
                 li[u] = e < PT * PT * TT ? (t * PT + kl) * (PT + 2) + nl : -1;
-                v[u] = ok ? d.src[(long)(d.flip_t ? TT - 1 - t : t) * d.st + (long)k * d.sk + (long)n * d.sn] : 0.f;
+                // unconditional loads from clamped (in-range) addresses, selected afterwards: `ok ? src[..] : 0` compiles to a
+                // branch per load with a wait of its own, i.e. ONE load in flight per thread instead of four
+                const int tc = t < TT ? t : TT - 1, kc = k < d.K ? k : d.K - 1, nc = n < d.N ? n : d.N - 1;
+                v[u] = d.src[(long)(d.flip_t ? TT - 1 - tc : tc) * d.st + (long)kc * d.sk + (long)nc * d.sn];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u]));       // (keeps hipcc from sinking the loads under `ok`)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ok[u] ? v[u] : 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (li[u] >= 0) tl[li[u]] = (T)v[u];
