@@ -248,3 +248,41 @@ def test_maxpool_with_transform_is_exact_on_integer_data():
     unique = ((a4 == mx).sum((3, 5), keepdim=True) == 1).expand_as(a4).reshape(N, C, H, W).permute(0, 2, 3, 1)
     assert unique.float().mean().item() > 0.5
     assert torch.equal(da.float().cpu()[unique], act.grad.permute(0, 2, 3, 1)[unique])
+
+
+@pytest.mark.parametrize("R,stride,pad,Ci,Co,H,W", [(3, 2, 1, 64, 128, 11, 13), (1, 2, 0, 128, 64, 11, 13), (3, 2, 1, 256, 256, 28, 28),
+                                                   (1, 1, 0, 1024, 256, 14, 14), (7, 2, 3, 64, 64, 20, 17)])
+def test_strided_convs_are_exact_on_integer_data(R, stride, pad, Ci, Co, H, W):
+    """TransUNet's strided / 1x1 bottleneck convs on the tap-gather MFMA kernels (reference
+    TransUnet/vit_seg_modeling_resnet_skip.py:52-60): forward with a transform on load (zero padding applied AFTER it), the
+    fractionally-strided data gradient and the weight gradient."""
+    lib, ops = _gpu()
+    from umi.graph_tu import TUTape
+    g = torch.Generator().manual_seed(R * 100 + Ci)
+    N = 2
+    x = _ints((N, H, W, Ci), -2, 2, g)
+    w = _ints((Co, Ci, R, R), -1, 1, g)
+    t = _int_tx(Ci, g)
+    xa = _apply(x, t).permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xa, wr, None, stride, pad)
+    assert y_ref.abs().max().item() < 2048
+    gy = _ints(tuple(y_ref.shape), -1, 1, g)
+    y_ref.backward(gy)
+    assert xa.grad.abs().max().item() < 2048
+    Ho, Wo = y_ref.shape[2:]
+    xd, td, wd = x.half().to(DEV), t.to(DEV), w.to(DEV)
+    y = torch.empty(N, Ho, Wo, Co, device=DEV, dtype=torch.float16)
+    assert ops.conv_plan(xd, y, R, R, stride, pad)[0] == 1
+    ops.conv_fwd(xd, td, lambda l: ops.pack_conv_fwd(wd, torch.float16, k8=bool(l)), None, y, R, R, stride, pad)
+    assert torch.equal(y.float().cpu(), y_ref.detach().permute(0, 2, 3, 1))
+    gyd = gy.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    dx = torch.empty(N, H, W, Ci, device=DEV, dtype=torch.float16)
+    if stride > 1 or R > 1:
+        TUTape._strided_dgrad(gyd, lambda l: ops.pack_conv_dgrad_strided(wd, torch.float16, k8=bool(l)), dx, R, R, stride, pad)
+    else:
+        ops.conv_fwd(gyd, None, lambda l: ops.pack_conv_dgrad(wd, torch.float16, k8=bool(l)), None, dx, 1, 1, 1, 0)
+    assert torch.equal(dx.float().cpu(), xa.grad.permute(0, 2, 3, 1))
+    dW = torch.empty(Co, Ci, R, R, device=DEV)
+    ops.conv_wgrad(xd, td, gyd, None, dW, Ci * R * R, R * R, 1, 1.0, R, R, stride, pad)
+    assert torch.equal(dW.cpu(), wr.grad)

@@ -140,6 +140,37 @@ __global__ __launch_bounds__(256) void optim_multi_kernel(const OptDesc* __restr
 // destination order -- the path below -- reads 4 bytes per 36-byte stride at best and a different line per lane at worst
 // (1.26 GB in 0.50 ms on the TransUNet's 105 M parameters, 0.18 ms on the U-Net's 31 M).
 constexpr int PT = 32;
+template <typename T, int U>
+__device__ __forceinline__ void pack_stage(const PackDesc& d, T* tl, int k0, int n0, bool k_inner) {
+    const int TT = d.T;
+    for (int e0 = threadIdx.x; e0 < PT * PT * TT; e0 += 256 * U) {
+        float v[U];
+        int li[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            const int o_ = e / (PT * TT), r = e - o_ * (PT * TT);
+            const int i_ = r / TT, t = r - i_ * TT;
+            const int kl = k_inner ? i_ : o_, nl = k_inner ? o_ : i_;
+            const int k = k0 + kl, n = n0 + nl;
+            ok[u] = e < PT * PT * TT && k < d.K && n < d.N;
+            li[u] = e < PT * PT * TT ? (t * PT + kl) * (PT + 2) + nl : -1;
+            // unconditional loads from clamped (in-range) addresses, selected afterwards: `ok ? src[..] : 0` compiles to a
+            // branch per load with a wait of its own, i.e. ONE load in flight per thread instead of U
+            const int tc = t < TT ? t : TT - 1, kc = k < d.K ? k : d.K - 1, nc = n < d.N ? n : d.N - 1;
+            v[u] = d.src[(long)(d.flip_t ? TT - 1 - tc : tc) * d.st + (long)kc * d.sk + (long)nc * d.sn];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(v[u]));       // (keeps hipcc from sinking the loads under `ok`)
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ok[u] ? v[u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (li[u] >= 0) tl[li[u]] = (T)v[u];
+    }
+}
+
 template <typename T>
 __device__ void pack_tiles_k8(const PackDesc& d, int my_blk, int n_blk) {
     __shared__ T tl[9 * PT * (PT + 2)];                       // [t][k][n], row pad 2
@@ -149,33 +180,10 @@ __device__ void pack_tiles_k8(const PackDesc& d, int my_blk, int n_blk) {
     T* dst = (T*)d.dst;
     for (int tile = my_blk; tile < nkt * nnt; tile += n_blk) {
         const int k0 = (tile % nkt) * PT, n0 = (tile / nkt) * PT;
-        // four loads in flight per thread (a one-load loop runs at the memory latency: 36 trips per tile at T = 9)
-        for (int e0 = threadIdx.x; e0 < PT * PT * TT; e0 += 1024) {
-            float v[4];
-            int li[4];
-            bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + 256 * u;
-                const int o_ = e / (PT * TT), r = e - o_ * (PT * TT);
-                const int i_ = r / TT, t = r - i_ * TT;
-                const int kl = k_inner ? i_ : o_, nl = k_inner ? o_ : i_;
-                const int k = k0 + kl, n = n0 + nl;
-                ok[u] = e < PT * PT * TT && k < d.K && n < d.N;
-                li[u] = e < PT * PT * TT ? (t * PT + kl) * (PT + 2) + nl : -1;
-                // unconditional loads from clamped (in-range) addresses, selected afterwards: `ok ? src[..] : 0` compiles to a
-                // branch per load with a wait of its own, i.e. ONE load in flight per thread instead of four
-                const int tc = t < TT ? t : TT - 1, kc = k < d.K ? k : d.K - 1, nc = n < d.N ? n : d.N - 1;
-                v[u] = d.src[(long)(d.flip_t ? TT - 1 - tc : tc) * d.st + (long)kc * d.sk + (long)nc * d.sn];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u]));       // (keeps hipcc from sinking the loads under `ok`)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ok[u] ? v[u] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (li[u] >= 0) tl[li[u]] = (T)v[u];
-        }
+        // U loads in flight per thread (a one-load loop runs at the memory latency: 36 trips per tile at T = 9): 12 for the
+        // 3 x 3 convs' tiles (three trips), 4 otherwise (a T = 1 tile is one trip of four)
+        if (TT == 9) pack_stage<T, 12>(d, tl, k0, n0, k_inner);
+        else pack_stage<T, 4>(d, tl, k0, n0, k_inner);
         __syncthreads();
         // pieces of 8 k for one (t, k-group, n): 16 bytes (fp16) each, 32 n adjacent
         for (int e = threadIdx.x; e < TT * (PT / 8) * PT; e += 256) {
