@@ -441,9 +441,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
         } else {
         // ---- K32: three tap-column stages per 32-channel super-chunk -------------------------------------------------------
         // Invariant at the top of stage st: weight buffer st & 1 holds stage st (written one stage earlier, behind a barrier), the
-        // registers hold stage st + 1, which is written into the other buffer now -- every wave left that buffer at the barrier
-        // that ended stage st - 1 -- and stage st + 2 is requested.  The halo tile has one buffer: it is written at the top of a
-        // super-chunk's first stage, with a barrier of its own in front of the fragment reads.
+        // registers hold stage st + 1, which is written into the other buffer at the END of this stage's MFMA phase -- every wave
+        // left that buffer at the barrier that ended stage st - 1 -- and stage st + 2 is requested behind the writes.  The halo tile
+        // has one buffer: it is written at the top of a super-chunk's first stage, with a barrier of its own in front of the
+        // fragment reads.
 #pragma unroll
         for (int k = 0; k < C::KPW; ++k) *reinterpret_cast<half8*>(smem + wkl_base + k * 64 * C::WROWB) = wraw[k];
 #pragma unroll
@@ -469,11 +470,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                 for (int k = 0; k < C::KPH; ++k)
                     *reinterpret_cast<half8*>(smem + (k == C::KPH - 1 ? hl_last : (hoff[k] != OOB ? hl_a : hl_b) + k * C::HPASS * HROWB)) = hraw[k];
             }
-            if (st + 1 < nst) {
-#pragma unroll
-                for (int k = 0; k < C::KPW; ++k)
-                    *reinterpret_cast<half8*>(smem + wkl_base + (C::WSTG - wcur) + k * 64 * C::WROWB) = wraw[k];
-            }
 #ifdef UMI_STAMP
             UMI_T(t1);
 #endif
@@ -488,10 +484,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                     txr = UMI_TX_ROWS(txc);
                 }
                 if (sci + 1 < nsc) UMI_ISSUE_H(sci + 1);   // in flight for three MFMA phases
-            }
-            {
-                const int ndx = dx == 0 ? 2 : dx - 1, nsci = dx == 0 ? sci : sci + 1;      // stage st + 2
-                if (st + 2 < nst) UMI_ISSUE_WK(nsci, ndx);
             }
             __builtin_amdgcn_s_setprio(3);
             {
@@ -519,6 +511,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
                         }
                     }
             }
+            // The next stage's weights (registers, loaded one stage ago) go to the OTHER buffer -- free since the barrier that ended
+            // the previous stage -- and the stage after that is requested, both at the END of this stage's MFMA phase: behind its
+            // last fragment read (hipcc orders an LDS write after every earlier LDS read of the same array, so pinning the writes any
+            // earlier makes the whole pinned order unsatisfiable and it is dropped) and between its last twelve MFMAs.  At the top
+            // of the stage -- where they used to sit, in front of the phase's first fragment reads in the same LDS queue -- they
+            // delayed the first MFMA by their own latency: profiles/r03_conv_fwd_ab_weight_staging.txt (no staging at all +18 %,
+            // no writes +10 %, no loads +7 % on the 17 launches; this placement +1.6...3.2 %, outputs bit-identical).  Branch-free:
+            // the last stage writes stale registers into a buffer nobody reads again, the last two re-request an existing stage.
+            {
+#pragma unroll
+                for (int k = 0; k < C::KPW; ++k)
+                    *reinterpret_cast<half8*>(smem + wkl_base + (C::WSTG - wcur) + k * 64 * C::WROWB) = wraw[k];
+                const int ndx = dx == 0 ? 2 : dx - 1;
+                int nsci = dx == 0 ? sci : sci + 1;                                            // stage st + 2
+                nsci = nsci < nsc ? nsci : nsc - 1;
+                UMI_ISSUE_WK(nsci, ndx);
+            }
             // issue order: the 6 weight fragments and the first 4 pixel fragments up front, then one pixel fragment behind every
             // (halo row, half) group of MFMAs -- four groups (>= 8 MFMAs) ahead of its use
 #define UMI_G(n_) __builtin_amdgcn_sched_group_barrier(0x008, n_, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
@@ -526,7 +535,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
             UMI_G(2); UMI_G(2); UMI_G(4); UMI_G(4);
             UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6);
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            // the last twelve MFMAs carry the weight writes (one per 2; per 4 with the 64-channel tile's three pieces), the requests
+            // of the stage after next follow them
+#pragma unroll
+            for (int i_ = 0; i_ < C::KPW; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 12 / C::KPW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, C::KPW, 0);
 #undef UMI_G
             __builtin_amdgcn_s_setprio(0);
 #ifdef UMI_STAMP
