@@ -535,14 +535,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
             UMI_G(2); UMI_G(2); UMI_G(4); UMI_G(4);
             UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6);
-            // the last twelve MFMAs carry the weight writes (one per 2; per 4 with the 64-channel tile's three pieces), the requests
-            // of the stage after next follow them
+            // the last twelve MFMAs carry the weight writes and the requests of the stage after next
+            // (tail orders measured, profiles/r03_conv_fwd_ab_weight_staging.txt: a write behind each of the first KPW MFMAs and a
+            //  request behind each following group, as here, 4.824 ms; a write per two MFMAs then all requests 4.859; all writes
+            //  first 4.942)
 #pragma unroll
             for (int i_ = 0; i_ < C::KPW; ++i_) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 12 / C::KPW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x020, C::KPW, 0);
+#pragma unroll
+            for (int i_ = 0; i_ < C::KPW; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, (12 - C::KPW) / C::KPW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
 #undef UMI_G
             __builtin_amdgcn_s_setprio(0);
 #ifdef UMI_STAMP
