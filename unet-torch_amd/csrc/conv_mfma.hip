@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             UMI_T(t0b);
 #endif
             if (first) {
+#ifndef UMI_X_NOTX      /* timing-only ablations of the halo tile's staging: no transform / no LDS writes */
                 if (HAS_TX) {
                     float4 t[8];
 #pragma unroll
@@ -466,9 +467,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
 #pragma unroll
                     for (int k = 0; k < C::KPH; ++k) hraw[k] = umi_tx8(hraw[k], t);
                 }
+#endif
+#ifdef UMI_X_NOHW
+#pragma unroll
+                for (int k = 0; k < C::KPH; ++k) asm volatile("" ::"v"(hraw[k]));
+#else
 #pragma unroll
                 for (int k = 0; k < C::KPH; ++k)
                     *reinterpret_cast<half8*>(smem + (k == C::KPH - 1 ? hl_last : (hoff[k] != OOB ? hl_a : hl_b) + k * C::HPASS * HROWB)) = hraw[k];
+#endif
             }
 #ifdef UMI_STAMP
             UMI_T(t1);
@@ -516,17 +523,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             // last fragment read (hipcc orders an LDS write after every earlier LDS read of the same array, so pinning the writes any
             // earlier makes the whole pinned order unsatisfiable and it is dropped) and between its last twelve MFMAs.  At the top
             // of the stage -- where they used to sit, in front of the phase's first fragment reads in the same LDS queue -- they
-            // delayed the first MFMA by their own latency: profiles/r03_conv_fwd_ab_weight_staging.txt (no staging at all +18 %,
+            // delayed the first MFMA by their own latency: profiles/r03_conv_fwd_ab_staging_ablations.txt (no staging at all +18 %,
             // no writes +10 %, no loads +7 % on the 17 launches; this placement +1.6...3.2 %, outputs bit-identical).  Branch-free:
             // the last stage writes stale registers into a buffer nobody reads again, the last two re-request an existing stage.
+            // (UMI_X_*: timing-only ablation builds, tools/build_variant.py NAME conv_mfma.hip -DUMI_X_...; results are wrong by construction)
             {
+#ifdef UMI_X_NOWWRITE
+#pragma unroll
+                for (int k = 0; k < C::KPW; ++k) asm volatile("" ::"v"(wraw[k]));
+#else
 #pragma unroll
                 for (int k = 0; k < C::KPW; ++k)
                     *reinterpret_cast<half8*>(smem + wkl_base + (C::WSTG - wcur) + k * 64 * C::WROWB) = wraw[k];
+#endif
+#ifndef UMI_X_NOWLOAD
                 const int ndx = dx == 0 ? 2 : dx - 1;
                 int nsci = dx == 0 ? sci : sci + 1;                                            // stage st + 2
                 nsci = nsci < nsc ? nsci : nsc - 1;
                 UMI_ISSUE_WK(nsci, ndx);
+#endif
             }
             // issue order: the 6 weight fragments and the first 4 pixel fragments up front, then one pixel fragment behind every
             // (halo row, half) group of MFMAs -- four groups (>= 8 MFMAs) ahead of its use
@@ -536,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(
             UMI_G(2); UMI_G(2); UMI_G(4); UMI_G(4);
             UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6); UMI_G(6);
             // the last twelve MFMAs carry the weight writes and the requests of the stage after next
-            // (tail orders measured, profiles/r03_conv_fwd_ab_weight_staging.txt: a write behind each of the first KPW MFMAs and a
+            // (tail orders measured, profiles/r03_conv_fwd_ab_staging_ablations.txt: a write behind each of the first KPW MFMAs and a
             //  request behind each following group, as here, 4.824 ms; a write per two MFMAs then all requests 4.859; all writes
             //  first 4.942)
 #pragma unroll
